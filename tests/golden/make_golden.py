@@ -300,7 +300,7 @@ def per_fixtures():
         aux = np.random.RandomState(900 + seed)  # abs-error source, separate stream
         mem = P.Memory(cap)
         ops = []          # (kind, n)
-        b_idx, isw, errs, betas = [], [], [], []
+        b_idx, isw, errs, betas, pss = [], [], [], [], []
         stored = 0
         n = 4 if cap == 8 else 32
         # fill a little, then interleave store / sample / batch_update like
@@ -325,7 +325,12 @@ def per_fixtures():
             if n_rounds % 5 == 0:
                 e[: n // 4] = 0.0  # exercise the +epsilon floor
             errs.append(e.copy())
+            # what Memory.batch_update computes from e (BrainPrioritizedReplyDQN.py:147-149), kept
+            # because NumPy's float32 power is not correctly rounded (differs from libm by 1 ulp)
+            pss.append(np.power(np.minimum(e + np.float32(0.01), np.float32(1.0)), 0.6).astype(np.float32))
             mem.batch_update(idx, e)  # note: mutates e in place (+= 0.01)
+            for ti, pv in zip(idx, pss[-1]):
+                assert mem.sum_tree.tree[ti] == pv or list(idx).count(ti) > 1
             b_idx.append(idx.copy())
             isw.append(w[:, 0].copy())
             betas.append(float(mem.beta))
@@ -335,6 +340,7 @@ def per_fixtures():
         out[name + "_b_idx"] = np.array(b_idx, np.int32)
         out[name + "_isw"] = np.array(isw, np.float64)
         out[name + "_abs_err"] = np.array(errs, np.float32)
+        out[name + "_ps"] = np.array(pss, np.float32)
         out[name + "_beta"] = np.array(betas, np.float64)
         if cap <= 1000:
             out[name + "_tree"] = t.tree.copy()
