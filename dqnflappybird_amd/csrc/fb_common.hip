@@ -1,0 +1,48 @@
+// fb_common.hip -- error channel, version, host-side MT19937 seeding.
+#include "fb_common.h"
+
+thread_local char fb_err_buf[512] = "";
+
+int fb_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(fb_err_buf, sizeof(fb_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *fb_last_error(void) { return fb_err_buf; }
+extern "C" int fb_version(void) { return 100; }
+
+extern "C" int fb_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fb_set_error(FB_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+// Matsumoto & Nishimura mt19937ar.c seeding (CPython random.seed / numpy legacy seed use these)
+void fb_mt_init_genrand_host(FbMT *s, uint32_t seed) {
+    s->mt[0] = seed;
+    for (int i = 1; i < 624; i++) s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->idx = 624;
+}
+
+void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int key_length) {
+    fb_mt_init_genrand_host(s, 19650218u);
+    uint32_t *mt = s->mt;
+    int i = 1, j = 0, k = 624 > key_length ? 624 : key_length;
+    for (; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (j >= key_length) j = 0;
+    }
+    for (k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+    s->idx = 624;
+}

@@ -1,0 +1,423 @@
+// fb_env.hip -- batched headless Flappy Bird with the 80x80 preprocess fused in (gfx950).
+//
+// Reference semantics (paths relative to the reference checkout):
+//   GameState.__init__ / frame_step   game/wrapped_flappy_bird.py:59-183
+//   getRandomPipe                     game/wrapped_flappy_bird.py:208-221
+//   checkCrash / pixelCollision       game/wrapped_flappy_bird.py:244-300
+//   preprocess                        FlappyBirdDQN.py:31-34
+//
+// Design (DESIGN.md "Kernel E"):  one 256-thread workgroup walks envs e = blockIdx.x, +gridDim.x.
+// The pipe / bird sprites (palette indices), the palette, the resize tap tables and a
+// pre-rendered table of the ground region live in LDS (25 KB, staged once per workgroup).
+// The 288x512x3 canvas of the reference is never built: every output pixel of the 80x80
+// observation reads the four canvas pixels cv2.resize would read, resolved directly against the
+// sprite that is on top there, then applies OpenCV's fixed-point bilinear / gray / threshold.
+// Output columns c >= 63 only ever see the ground sprite (taps y >= 405, base drawn last over the
+// pipes, bird never below y = 403), so they depend on basex alone (12 values) and come from a
+// table computed at create time.  Pixels are emitted 64 at a time as one ballot word (the replay
+// ring stores 1 bit / pixel) and optionally as u8 {0,255}.
+#include "fb_common.h"
+
+namespace {
+
+constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H = 24;
+constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
+constexpr int GROUND_C0 = 63;    // first observation column whose taps all lie in the ground sprite
+constexpr size_t BLOB_BYTES = 8 + 4 + 1024 + PIPE_H * PIPE_W + 3 * BIRD_H * BIRD_W + BASE_H * BASE_W;
+
+struct alignas(16) EnvLds {      // staged into LDS by every workgroup
+    uint32_t pal[256];
+    uint8_t pipe[PIPE_H * PIPE_W];
+    uint8_t bird[3 * BIRD_H * BIRD_W];
+    uint32_t ground_bits[12 * OBS];      // [basex / -4][r] bit (c - 63)
+    int16_t xo[OBS], xb0[OBS], xb1[OBS]; // game-x taps per output row r (cv vertical pass)
+    int16_t yo[OBS], ya0[OBS], ya1[OBS]; // game-y taps per output column c (cv horizontal pass)
+};
+static_assert(sizeof(EnvLds) % 16 == 0, "EnvLds must be a multiple of 16 bytes");
+
+struct EnvConst {
+    EnvLds l;
+    uint8_t base[BASE_H * BASE_W];       // only fb_env_render_full needs the raw ground sprite
+};
+
+struct EnvParams {
+    int n_envs;
+    uint32_t seed_lo, seed_hi;
+    int tape_len;
+    const int8_t *tape;                  // [n_envs][tape_len] or null
+    int32_t *state;                      // [n_envs][16]
+    const EnvConst *cst;
+    unsigned long long *err_count;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ int gap_y(int idx) { return 100 + 10 * idx; }   // 20+10*idx + int(404.48*0.2)
+
+__device__ __forceinline__ int draw_gap(const EnvParams &p, int env, int32_t *st) {
+    if (p.tape_len > 0) {
+        int cur = st[15];
+        int v = cur < p.tape_len ? p.tape[(size_t)env * p.tape_len + cur] : 0;
+        st[15] = cur + 1;
+        return v & 7;
+    }
+    fb_u4 o = fb_philox(p.seed_lo, p.seed_hi, (uint32_t)env, (uint32_t)st[14], FB_STREAM_GAP, 0u);
+    st[14] += 1;
+    return (int)(o.x >> 29);
+}
+
+__device__ __forceinline__ void env_reset(const EnvParams &p, int env, int32_t *st) {   // :59-85
+    st[0] = 244; st[1] = 0; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0; st[6] = 2;
+    int g1 = draw_gap(p, env, st), g2 = draw_gap(p, env, st);
+    st[7] = 288; st[8] = 432; st[9] = 0;
+    st[10] = g1; st[11] = g2; st[12] = 0;
+}
+
+// palette index of the topmost pipe pixel at canvas (x, y), 0 if none; y < BASEY_I
+__device__ __forceinline__ int pipe_at(const EnvLds &L, const int32_t *st, int x, int y) {
+    int idx = 0;
+    const int n = st[6];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int col = x - st[7 + i];
+        if (i < n && col >= 0 && col < PIPE_W) {
+            int gy = gap_y(st[10 + i]);
+            if (y < gy) idx = L.pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];   // upper = rotated by 180
+            else if (y >= gy + GAP) idx = L.pipe[(y - gy - GAP) * PIPE_W + col];
+        }
+    }
+    return idx;
+}
+
+__device__ __forceinline__ int bird_at(const EnvLds &L, const int32_t *st, int x, int y) {
+    int bx = x - PLAYERX, by = y - st[0];
+    if (bx >= 0 && bx < BIRD_W && by >= 0 && by < BIRD_H) return L.bird[(st[2] * BIRD_H + by) * BIRD_W + bx];
+    return 0;
+}
+
+// OpenCV 8-bit INTER_LINEAR on 3 channels + BGR2GRAY (on RGB-ordered data) + threshold(>1)
+__device__ __forceinline__ int resize_gray_bit(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11,
+                                               int a0, int a1, int b0, int b1) {
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int h0 = (int)((s00 >> (8 * k)) & 255u) * a0 + (int)((s01 >> (8 * k)) & 255u) * a1;
+        int h1 = (int)((s10 >> (8 * k)) & 255u) * a0 + (int)((s11 >> (8 * k)) & 255u) * a1;
+        v[k] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    }
+    int gray = (v[0] * 1868 + v[1] * 9617 + v[2] * 4899 + (1 << 13)) >> 14;
+    return gray > 1;
+}
+
+// ------------------------------------------------------------------ the step kernel
+template <bool STEP>
+__global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
+                                                  uint8_t *__restrict__ frames,
+                                                  unsigned long long *__restrict__ frame_bits,
+                                                  float *__restrict__ reward, uint8_t *__restrict__ terminal,
+                                                  int32_t *__restrict__ score) {
+    __shared__ EnvLds L;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
+        uint4 *dst = reinterpret_cast<uint4 *>(&L);
+        for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int env = blockIdx.x; env < p.n_envs; env += gridDim.x) {
+        int32_t st[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[i] = p.state[(size_t)env * 16 + i];
+
+        float rew = 0.1f;
+        int term = 0, score_ret = st[5], bad = 0;
+        if (STEP) {
+            const int act = actions[env];
+            bad = act > 1;                                         // ValueError('Multiple input actions!'), :99-100
+            if (!bad) {
+                int flapped = 0;
+                if (act == 1 && st[0] > -2 * BIRD_H) { st[1] = -9; flapped = 1; }     // :105-108
+                if (st[1] < 10 && !flapped) st[1] += 1;                               // :110-111
+                const int ynew = st[0] + st[1];                   // min(velY, 380.48 - y), :115
+                const int ground = ynew >= 380;                   // y + 24 >= 403.48, :252
+                st[0] = ynew < 0 ? 0 : ynew;                      // :116-117
+                if ((st[3] + 1) % 3 == 0) {                       // :120-121, cycle([0,1,2,1])
+                    const int cyc = st[13] & 3;
+                    st[2] = cyc == 3 ? 1 : cyc;
+                    st[13] = (cyc + 1) & 3;
+                }
+                st[3] = (st[3] + 1) % 30;                         // :122
+                st[4] = -((-st[4] + 100) % 48);                   // :123
+#pragma unroll
+                for (int i = 0; i < 3; i++) if (i < st[6]) st[7 + i] -= 4;            // :126-128
+                if (0 < st[7] && st[7] < 5) {                     // :131-134
+                    const int g = draw_gap(p, env, st);
+                    if (st[6] == 2) { st[9] = 298; st[12] = g; } else { st[8] = 298; st[11] = g; }
+                    st[6] += 1;
+                }
+                if (st[7] < -PIPE_W) {                            // :137-139
+                    st[7] = st[8]; st[10] = st[11]; st[8] = st[9]; st[11] = st[12]; st[9] = 0; st[12] = 0;
+                    st[6] -= 1;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++)                       // :142-148: x+26 <= 74 < x+30
+                    if (i < st[6] && st[7 + i] <= 48 && st[7 + i] > 44) { st[5] += 1; rew = 3.0f; }
+                // pixel-exact pipe collision, :255-273 -- every bird pixel against the pipe on top of it
+                int hit = 0;
+                if (!ground) {
+                    for (int i = threadIdx.x; i < BIRD_W * BIRD_H; i += 256) {
+                        const int bx = i % BIRD_W, by = i / BIRD_W;
+                        if (L.bird[(st[2] * BIRD_H + by) * BIRD_W + bx]) {
+                            const int y = st[0] + by;
+                            if (y < BASEY_I && pipe_at(L, st, PLAYERX + bx, y)) hit = 1;
+                        }
+                    }
+                }
+                const int crash = __syncthreads_or(hit | ground);
+                score_ret = st[5];                                // :155
+                if (crash) { term = 1; env_reset(p, env, st); rew = -3.0f; }          // :157-162
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (STEP) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) p.state[(size_t)env * 16 + i] = st[i];
+                reward[env] = bad ? 0.f : rew;
+                terminal[env] = (uint8_t)term;
+                score[env] = score_ret;
+                if (bad) atomicAdd(p.err_count, 1ull);
+            }
+        }
+        // ---- observation: 100 ballot words of 64 pixels, p = r*80 + c
+        const int gidx = (-st[4]) >> 2;                           // basex in {0,-4,..,-44}
+        for (int w = wave; w < 100; w += 4) {
+            const int pix = w * 64 + lane;
+            const int r = pix / OBS, c = pix - r * OBS;
+            int bit;
+            if (c >= GROUND_C0) {
+                bit = (L.ground_bits[gidx * OBS + r] >> (c - GROUND_C0)) & 1;
+            } else {
+                const int x0 = L.xo[r], y0 = L.yo[c];
+                int i00 = bird_at(L, st, x0, y0), i01 = bird_at(L, st, x0, y0 + 1);
+                int i10 = bird_at(L, st, x0 + 1, y0), i11 = bird_at(L, st, x0 + 1, y0 + 1);
+                if (!i00) i00 = pipe_at(L, st, x0, y0);
+                if (!i01) i01 = pipe_at(L, st, x0, y0 + 1);
+                if (!i10) i10 = pipe_at(L, st, x0 + 1, y0);
+                if (!i11) i11 = pipe_at(L, st, x0 + 1, y0 + 1);
+                bit = 0;
+                if (i00 | i01 | i10 | i11)
+                    bit = resize_gray_bit(L.pal[i00], L.pal[i01], L.pal[i10], L.pal[i11], L.ya0[c], L.ya1[c],
+                                          L.xb0[r], L.xb1[r]);
+            }
+            const unsigned long long m = __ballot(bit);
+            if (frame_bits && lane == 0) frame_bits[(size_t)env * 100 + w] = m;
+            if (frames) frames[(size_t)env * 6400 + pix] = bit ? 255 : 0;
+        }
+        __syncthreads();                                          // keep the waves of this workgroup on the same env
+    }
+}
+
+// array3d of one env, for parity with the reference's image_data (:177)
+__global__ __launch_bounds__(256) void render_full_kernel(EnvParams p, int env, uint8_t *__restrict__ rgb) {
+    const EnvConst &C = *p.cst;
+    int32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = p.state[(size_t)env * 16 + i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < SW * SH; i += gridDim.x * 256) {
+        const int x = i / SH, y = i - x * SH;
+        int idx = bird_at(C.l, st, x, y);
+        if (!idx) {
+            if (y >= BASEY_I) { const int by = y - BASEY_I; idx = by < BASE_H ? C.base[by * BASE_W + (x - st[4])] : 0; }
+            else idx = pipe_at(C.l, st, x, y);
+        }
+        const uint32_t c = C.l.pal[idx];
+        rgb[(size_t)i * 3 + 0] = c & 255; rgb[(size_t)i * 3 + 1] = (c >> 8) & 255; rgb[(size_t)i * 3 + 2] = (c >> 16) & 255;
+    }
+}
+
+__global__ void env_reset_kernel(EnvParams p) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.n_envs) return;
+    int32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = 0;
+    env_reset(p, env, st);
+#pragma unroll
+    for (int i = 0; i < 16; i++) p.state[(size_t)env * 16 + i] = st[i];
+}
+
+// ------------------------------------------------------------------ host side
+// cv2.resize(.., (80,80)) INTER_LINEAR tap tables (OpenCV resize.cpp, 8-bit path)
+void linear_tab(int dst, int src, int16_t *ofs, int16_t *c0, int16_t *c1) {
+    const double scale = 1.0 / ((double)dst / src);
+    for (int d = 0; d < dst; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (s < 0) { s = 0; f = 0; }
+        if (s >= src - 1) { s = src - 1; f = 0; }
+        ofs[d] = (int16_t)s;
+        c0[d] = (int16_t)lrintf((1.f - f) * 2048.f);
+        c1[d] = (int16_t)lrintf(f * 2048.f);
+    }
+}
+
+int host_gray_bit(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11, int a0, int a1, int b0, int b1) {
+    int v[3];
+    for (int k = 0; k < 3; k++) {
+        int h0 = (int)((s00 >> (8 * k)) & 255u) * a0 + (int)((s01 >> (8 * k)) & 255u) * a1;
+        int h1 = (int)((s10 >> (8 * k)) & 255u) * a0 + (int)((s11 >> (8 * k)) & 255u) * a1;
+        v[k] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    }
+    return ((v[0] * 1868 + v[1] * 9617 + v[2] * 4899 + (1 << 13)) >> 14) > 1;
+}
+
+}  // namespace
+
+struct fb_env {
+    EnvParams p;
+    EnvConst *d_const;
+    int8_t *d_tape;
+    int grid;
+};
+
+extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const void *blob, size_t blob_bytes,
+                             fb_env_t *out) {
+    (void)flags;
+    FB_REQUIRE(out != nullptr, "fb_env_create: out is NULL");
+    FB_REQUIRE(n_envs > 0 && n_envs <= (1 << 22), "fb_env_create: n_envs=%d out of range", n_envs);
+    FB_REQUIRE(blob && blob_bytes == BLOB_BYTES && memcmp(blob, "FBSPR001", 8) == 0,
+               "fb_env_create: sprite blob must be %zu bytes with magic FBSPR001 (tools/make_assets.py)", BLOB_BYTES);
+    EnvConst *hc = new EnvConst();
+    const uint8_t *b = (const uint8_t *)blob + 12;
+    memcpy(hc->l.pal, b, 1024); b += 1024;
+    memcpy(hc->l.pipe, b, sizeof(hc->l.pipe)); b += sizeof(hc->l.pipe);
+    memcpy(hc->l.bird, b, sizeof(hc->l.bird)); b += sizeof(hc->l.bird);
+    memcpy(hc->base, b, sizeof(hc->base));
+    linear_tab(OBS, SH, hc->l.yo, hc->l.ya0, hc->l.ya1);      // cv columns = game y (512)
+    linear_tab(OBS, SW, hc->l.xo, hc->l.xb0, hc->l.xb1);      // cv rows    = game x (288)
+    // the ground-only region: every tap of columns >= GROUND_C0 must be inside the ground sprite
+    if (hc->l.yo[GROUND_C0] < BASEY_I || hc->l.yo[GROUND_C0 - 1] + 1 >= BASEY_I) {
+        delete hc;
+        return fb_set_error(FB_ERR_INVALID, "fb_env_create: ground column split does not match the tap table");
+    }
+    for (int g = 0; g < 12; g++)
+        for (int r = 0; r < OBS; r++) {
+            uint32_t bits = 0;
+            for (int c = GROUND_C0; c < OBS; c++) {
+                uint32_t s[2][2];
+                for (int tx = 0; tx < 2; tx++)
+                    for (int ty = 0; ty < 2; ty++) {
+                        int x = hc->l.xo[r] + tx, y = hc->l.yo[c] + ty;
+                        s[tx][ty] = hc->l.pal[hc->base[(y - BASEY_I) * BASE_W + (x + 4 * g)]];
+                    }
+                bits |= (uint32_t)host_gray_bit(s[0][0], s[0][1], s[1][0], s[1][1], hc->l.ya0[c], hc->l.ya1[c],
+                                                hc->l.xb0[r], hc->l.xb1[r]) << (c - GROUND_C0);
+            }
+            hc->l.ground_bits[g * OBS + r] = bits;
+        }
+    fb_env *h = new fb_env();
+    memset(h, 0, sizeof(*h));
+    hipError_t e = hipMalloc(&h->d_const, sizeof(EnvConst));
+    if (e == hipSuccess) e = hipMemcpy(h->d_const, hc, sizeof(EnvConst), hipMemcpyHostToDevice);
+    delete hc;
+    if (e == hipSuccess) e = hipMalloc(&h->p.state, sizeof(int32_t) * 16 * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMalloc(&h->p.err_count, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->p.err_count, 0, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        fb_set_error(FB_ERR_HIP, "fb_env_create: %s", hipGetErrorString(e));
+        fb_env_destroy(h);
+        return FB_ERR_HIP;
+    }
+    h->p.n_envs = n_envs;
+    h->p.seed_lo = (uint32_t)seed; h->p.seed_hi = (uint32_t)(seed >> 32);
+    h->p.cst = h->d_const;
+    h->grid = n_envs < 2048 ? n_envs : 2048;
+    *out = h;
+    return fb_env_reset(h, nullptr);
+}
+
+extern "C" int fb_env_destroy(fb_env_t h) {
+    if (!h) return FB_OK;
+    if (h->d_const) (void)hipFree(h->d_const);
+    if (h->p.state) (void)hipFree(h->p.state);
+    if (h->p.err_count) (void)hipFree(h->p.err_count);
+    if (h->d_tape) (void)hipFree(h->d_tape);
+    delete h;
+    return FB_OK;
+}
+
+extern "C" int fb_env_reset(fb_env_t h, void *stream) {
+    FB_REQUIRE(h, "fb_env_reset: NULL handle");
+    hipLaunchKernelGGL(env_reset_kernel, dim3((h->p.n_envs + 255) / 256), dim3(256), 0, fb_stream(stream), h->p);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
+                           uint8_t *terminal, int32_t *score, void *stream) {
+    FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
+    hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid), dim3(256), 0, fb_stream(stream), h->p, actions, frames,
+                       (unsigned long long *)frame_bits, reward, terminal, score);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits, void *stream) {
+    FB_REQUIRE(h && (frames || frame_bits), "fb_env_observe: NULL argument");
+    hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(256), 0, fb_stream(stream), h->p,
+                       (const uint8_t *)nullptr, frames, (unsigned long long *)frame_bits, (float *)nullptr,
+                       (uint8_t *)nullptr, (int32_t *)nullptr);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_env_get_state(fb_env_t h, int32_t *state_host) {
+    FB_REQUIRE(h && state_host, "fb_env_get_state: NULL argument");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    FB_CHECK_HIP(hipMemcpy(state_host, h->p.state, sizeof(int32_t) * 16 * (size_t)h->p.n_envs, hipMemcpyDeviceToHost));
+    return FB_OK;
+}
+
+extern "C" int fb_env_set_state(fb_env_t h, const int32_t *state_host) {
+    FB_REQUIRE(h && state_host, "fb_env_set_state: NULL argument");
+    for (int e = 0; e < h->p.n_envs; e++) {
+        const int32_t *s = state_host + (size_t)e * 16;
+        FB_REQUIRE(s[6] >= 1 && s[6] <= 3 && s[2] >= 0 && s[2] <= 2 && s[4] <= 0 && s[4] > -48 && (s[4] & 3) == 0 &&
+                       s[10] >= 0 && s[10] < 8 && s[11] >= 0 && s[11] < 8 && s[12] >= 0 && s[12] < 8,
+                   "fb_env_set_state: env %d has an impossible state", e);
+    }
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    FB_CHECK_HIP(hipMemcpy(h->p.state, state_host, sizeof(int32_t) * 16 * (size_t)h->p.n_envs, hipMemcpyHostToDevice));
+    return FB_OK;
+}
+
+extern "C" int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len) {
+    FB_REQUIRE(h && tape_len >= 0 && (tape_len == 0 || tape_host), "fb_env_set_gap_tape: bad argument");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    if (h->d_tape) { (void)hipFree(h->d_tape); h->d_tape = nullptr; }
+    h->p.tape = nullptr; h->p.tape_len = 0;
+    if (tape_len > 0) {
+        size_t n = (size_t)h->p.n_envs * tape_len;
+        FB_CHECK_HIP(hipMalloc(&h->d_tape, n));
+        FB_CHECK_HIP(hipMemcpy(h->d_tape, tape_host, n, hipMemcpyHostToDevice));
+        h->p.tape = h->d_tape; h->p.tape_len = tape_len;
+    }
+    return FB_OK;
+}
+
+extern "C" int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream) {
+    FB_REQUIRE(h && rgb && env_id >= 0 && env_id < h->p.n_envs, "fb_env_render_full: bad argument");
+    hipLaunchKernelGGL(render_full_kernel, dim3(144), dim3(256), 0, fb_stream(stream), h->p, env_id, rgb);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_env_error_count(fb_env_t h, int64_t *count_host) {
+    FB_REQUIRE(h && count_host, "fb_env_error_count: NULL argument");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    FB_CHECK_HIP(hipMemcpy(&v, h->p.err_count, sizeof(v), hipMemcpyDeviceToHost));
+    *count_host = (int64_t)v;
+    return FB_OK;
+}

@@ -1,0 +1,93 @@
+"""Vectorised front end of the HIP hot path: N envs / N-env replay / Q-network as torch-ROCm
+tensors over the C ABI (include/fbdqn.h).  PyTorch is plumbing here (device memory, streams,
+torch.distributed); every computation is a kernel of libfbdqn.so.
+
+Reference counterparts:
+    VecGameState  -> game/wrapped_flappy_bird.py GameState, N at a time, preprocess fused in
+    VecReplay     -> BrainDQN.replayMemory (deque) / BrainPrioritizedReplyDQN.Memory
+    QNet          -> BrainDQN._createQNetwork / _trainQNetwork and the variants' versions
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("tensors handed to the HIP path must be contiguous CUDA(ROCm) tensors")
+
+
+class VecGameState:
+    """N independent Flappy Bird games on the GPU (game/wrapped_flappy_bird.py:58-183)."""
+
+    def __init__(self, n_envs, seed=0, device="cuda"):
+        L.require_gpu()
+        self.n = int(n_envs)
+        self.device = torch.device(device)
+        self.h = C.c_void_p()
+        blob = L.sprite_blob()
+        L.check(L.lib().fb_env_create(self.n, seed, 0, blob, len(blob), C.byref(self.h)), "fb_env_create")
+        dev = self.device
+        self.frames = torch.empty((self.n, 80, 80), dtype=torch.uint8, device=dev)
+        self.frame_bits = torch.empty((self.n, 100), dtype=torch.int64, device=dev)
+        self.reward = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.terminal = torch.empty(self.n, dtype=torch.uint8, device=dev)
+        self.score = torch.empty(self.n, dtype=torch.int32, device=dev)
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            L.lib().fb_env_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def reset(self):
+        L.check(L.lib().fb_env_reset(self.h, L.current_stream()), "fb_env_reset")
+
+    def frame_step(self, actions, want_u8=True, frame_bits=None):
+        """actions: uint8[N] (0 = nothing, 1 = flap).  Returns (frames u8[N,80,80] or None,
+        reward f32[N], terminal u8[N], score i32[N]); the packed frame is in self.frame_bits
+        (or in `frame_bits` when given, e.g. a replay-ring slot)."""
+        _dev_check(actions, frame_bits)
+        if actions.dtype != torch.uint8 or actions.numel() != self.n:
+            raise ValueError("actions must be uint8[N]")
+        fb = self.frame_bits if frame_bits is None else frame_bits
+        L.check(L.lib().fb_env_step(self.h, L.ptr(actions), L.ptr(self.frames) if want_u8 else None, L.ptr(fb),
+                                    L.ptr(self.reward), L.ptr(self.terminal), L.ptr(self.score),
+                                    L.current_stream()), "fb_env_step")
+        return (self.frames if want_u8 else None), self.reward, self.terminal, self.score
+
+    def observe(self):
+        L.check(L.lib().fb_env_observe(self.h, L.ptr(self.frames), L.ptr(self.frame_bits), L.current_stream()),
+                "fb_env_observe")
+        return self.frames
+
+    def get_state(self):
+        out = np.empty((self.n, 16), np.int32)
+        L.check(L.lib().fb_env_get_state(self.h, L.ptr(out)), "fb_env_get_state")
+        return out
+
+    def set_state(self, state):
+        state = np.ascontiguousarray(state, np.int32)
+        assert state.shape == (self.n, 16)
+        L.check(L.lib().fb_env_set_state(self.h, L.ptr(state)), "fb_env_set_state")
+
+    def set_gap_tape(self, tape):
+        if tape is None:
+            L.check(L.lib().fb_env_set_gap_tape(self.h, None, 0), "fb_env_set_gap_tape")
+            return
+        tape = np.ascontiguousarray(tape, np.int8)
+        assert tape.ndim == 2 and tape.shape[0] == self.n
+        L.check(L.lib().fb_env_set_gap_tape(self.h, L.ptr(tape), tape.shape[1]), "fb_env_set_gap_tape")
+
+    def render_full(self, env_id=0):
+        out = torch.empty((288, 512, 3), dtype=torch.uint8, device=self.device)
+        L.check(L.lib().fb_env_render_full(self.h, env_id, L.ptr(out), L.current_stream()), "fb_env_render_full")
+        return out
+
+    def error_count(self):
+        v = C.c_int64()
+        L.check(L.lib().fb_env_error_count(self.h, C.byref(v)), "fb_env_error_count")
+        return v.value

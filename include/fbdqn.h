@@ -1,0 +1,193 @@
+/*
+ * include/fbdqn.h -- C ABI of libfbdqn.so, the MI355X (gfx950) Flappy-Bird DQN hot path.
+ *
+ * This is the drop-in boundary.  The reference (angela000/DQNFlappyBird) is pure
+ * Python and has no FFI layer of its own; its boundary is the duck-typed surface
+ * FlappyBirdDQN.py uses (GameState.frame_step, Brain.getAction / setPerception).
+ * Each entry point below names the reference function it stands behind
+ * (paths relative to the reference checkout); the modules under dqnflappybird_amd/ bind them
+ * with ctypes and re-creates the reference's class surface on top.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is device memory owned by the CALLER (e.g.
+ *     torch.Tensor.data_ptr()); the library never frees caller memory;
+ *   - [host] pointers are ordinary host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     call is asynchronous on it unless documented otherwise; nothing here
+ *     allocates or synchronises inside the step functions, so a caller may
+ *     capture them into a hipGraph;
+ *   - return value: 0 = FB_OK, negative = error; fb_last_error() gives the text
+ *     (thread-local).  No C++ exception crosses the boundary;
+ *   - one handle per GPU; handles are not thread-safe; distinct handles are
+ *     independent.
+ */
+#ifndef FBDQN_H
+#define FBDQN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_OK 0
+#define FB_ERR_INVALID (-1)      /* bad argument / shape */
+#define FB_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define FB_ERR_NOMEM (-3)
+#define FB_ERR_STATE (-4)        /* call order (e.g. sample before enough pushes) */
+
+const char *fb_last_error(void);
+int fb_version(void);
+/* number of visible HIP devices, or a negative error; used by the shim to fail loudly */
+int fb_device_count(void);
+
+/* ------------------------------------------------------------------ environment
+ * N independent games stepped per launch, render + 80x80 preprocess fused in.
+ *   GameState.__init__    game/wrapped_flappy_bird.py:59-85
+ *   GameState.frame_step  game/wrapped_flappy_bird.py:87-183
+ *   getRandomPipe         game/wrapped_flappy_bird.py:208-221
+ *   checkCrash/pixelCollision  :244-300
+ *   flappy_bird_utils.load/getHitmask  game/flappy_bird_utils.py:16-124 (-> sprite blob)
+ *   preprocess            FlappyBirdDQN.py:31-34
+ */
+typedef struct fb_env *fb_env_t;
+
+#define FB_ENV_STATE_INTS 16     /* layout of one env in get/set_state, see below */
+
+/* sprite_blob: the packed sprites (tools/make_assets.py layout, 57 756 bytes) [host]. */
+int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const void *sprite_blob, size_t blob_bytes,
+                  fb_env_t *out);
+int fb_env_destroy(fb_env_t h);
+/* GameState.__init__ for every env (draws two pipe gaps each). */
+int fb_env_reset(fb_env_t h, void *stream);
+/* frame_step for every env.
+ *   actions   [dev] u8[N]      0 = do nothing, 1 = flap (index of the one-hot's 1); any other
+ *                              value is the reference's ValueError: the env is left untouched
+ *                              and counted in fb_env_error_count()
+ *   frames    [dev] u8[N,80,80] or NULL: preprocess(image_data) = {0,255}, [x_small][y_small]
+ *   frame_bits[dev] u64[N,100] or NULL: the same frame, 1 bit per pixel (bit i of the row-major
+ *                              pixel index i lives in word i/64, bit i%64)
+ *   reward    [dev] f32[N]     0.1 / 3 / -3
+ *   terminal  [dev] u8[N]
+ *   score     [dev] i32[N]     score_return (captured before the reset on a crash)
+ */
+int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
+                uint8_t *terminal, int32_t *score, void *stream);
+/* Observation of the current state without stepping (used for the very first frame only by
+ * tests; the reference obtains it with a do-nothing frame_step, FlappyBirdDQN.py:65-66). */
+int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits, void *stream);
+/* Parity / checkpoint access; synchronous.  i32[N][16] [host]:
+ *   0 playery 1 velY 2 playerIndex 3 loopIter 4 basex 5 score 6 nPipes
+ *   7..9 pipe x 10..12 pipe gap index (0..7) 13 PLAYER_INDEX_GEN phase 14 rng counter 15 tape cursor */
+int fb_env_get_state(fb_env_t h, int32_t *state_host);
+int fb_env_set_state(fb_env_t h, const int32_t *state_host);
+/* Replace the Philox pipe-gap stream by an explicit tape of random.randint(0,7) results
+ * (i8[N][tape_len], [host], copied); tape_len = 0 switches back to Philox. Synchronous. */
+int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len);
+/* pygame.surfarray.array3d of one env: u8[288,512,3] [dev] (debug / parity). */
+int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream);
+/* number of invalid actions seen so far (synchronous). */
+int fb_env_error_count(fb_env_t h, int64_t *count_host);
+
+/* ------------------------------------------------------------------ replay memory
+ * HBM ring of single frames (1 bit / pixel: preprocess only emits 0 or 255) + per-transition
+ * action / reward / terminal; a transition is the 5-frame window (s = t-3..t, s' = t-2..t+1).
+ *   deque store / popleft     BrainDQN.py:36,69-72      (REPLAY_MEMORY = 50000, :26)
+ *   frame stack               BrainDQN.py:68,238-239    (newest last, never reset)
+ *   random.sample             BrainDQN.py:197
+ *   minibatch assembly        BrainDQN.py:198-201
+ *   SumTree / Memory          BrainPrioritizedReplyDQN.py:32-151
+ */
+typedef struct fb_replay *fb_replay_t;
+
+#define FB_REPLAY_UNIFORM 0
+#define FB_REPLAY_PER 1
+
+#define FB_RNG_CPYTHON 0         /* MT19937 + Lib/random.py: bit-exact random.sample(range(n), B) */
+#define FB_RNG_PHILOX 1          /* counter based, with replacement, fully parallel */
+#define FB_RNG_NUMPY 2           /* MT19937 legacy np.random.seed(int): Memory.sample's uniform() */
+
+int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out);
+int fb_replay_destroy(fb_replay_t h);
+int fb_replay_seed(fb_replay_t h, int rng_kind, uint64_t seed);          /* synchronous */
+/* setInitState: the first observation becomes all four frames of every env's stack. */
+int fb_replay_reset(fb_replay_t h, const uint8_t *frames /*[dev] u8[N,80,80] or NULL*/,
+                    const uint64_t *frame_bits /*[dev] u64[N,100] or NULL*/, void *stream);
+/* setPerception's store: one transition per env (env order = deque order within a step).
+ * Exactly one of frames / frame_bits is given (the NEXT observation). */
+int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
+                   const float *rewards, const uint8_t *terminals, void *stream);
+/* currentState of every env: u8[N,80,80,4] [dev] (newest frame last). */
+int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream);
+/* Uniform: idx = deque positions (0 = oldest) exactly as random.sample(range(len), B).
+ * PER: idx = SumTree tree indices (b_idx of Memory.sample), isw = ISWeights[:,0] (f64),
+ *      uniforms = B doubles in [0,1) [dev] replacing np.random.uniform's stream, or NULL. */
+int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, void *stream);
+/* s, s2: u8[B,80,80,4]; a: u8[B]; r: f32[B]; t: u8[B]  (all [dev]) */
+int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a,
+                     float *r, uint8_t *t, void *stream);
+/* Memory.batch_update(tree_idx, abs_errors): abs_err f32[B] [dev] is updated in place (+= 0.01)
+ * like the reference does; priorities_or_null f32[B] [dev] injects the p values instead of
+ * computing (min(|e|+0.01, 1))^0.6 on the device. */
+int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err,
+                                const float *priorities_or_null, void *stream);
+/* host-side queries (synchronous): len(replayMemory); PER: tree copy f64[2*cap-1] [host] */
+int fb_replay_size(fb_replay_t h, int64_t *size_host);
+int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *data_pointer, int64_t *size, double *beta);
+
+/* ------------------------------------------------------------------ Q network
+ *   network        BrainDQN.py:119-155 (conv 8x8/4 -> pool -> conv 4x4/2 -> conv 3x3/1 -> fc -> A)
+ *   dueling head   BrainDuelingDQN.py:78-86
+ *   getAction      BrainDQN.py:99-116
+ *   _trainQNetwork BrainDQN.py:195-223, BrainDQNNature.py:149-182, BrainDoubleDQN.py:37-68,
+ *                  BrainPrioritizedReplyDQN.py:277-315
+ *   Adam           BrainDQN.py:163 (tf.train.AdamOptimizer(1e-6))
+ *   target sync    BrainDQNNature.py:107-111,151-152
+ * Flat fp32 parameter order = the reference's variable creation order:
+ *   W_conv1[8,8,4,32] b[32] W_conv2[4,4,32,64] b[64] W_conv3[3,3,64,64] b[64] W_fc1[1600,FC] b[FC]
+ *   then  W_fc2[FC,A] b[A]            (plain)
+ *   or    W_v[FC,1] b_v[1] W_a[FC,A] b_a[A]   (dueling)
+ */
+typedef struct fb_qnet *fb_qnet_t;
+
+#define FB_ARCH_PLAIN 0
+#define FB_ARCH_DUELING 1
+#define FB_NET_ONLINE 0
+#define FB_NET_TARGET 1
+#define FB_ALGO_DQN 0            /* BrainDQN: target from the same net, loss = sum */
+#define FB_ALGO_NATURE 1         /* BrainDQNNature: frozen target net, loss = mean */
+#define FB_ALGO_DOUBLE 2         /* BrainDoubleDQN.trainQNetwork: argmax online, value target, mean */
+#define FB_ALGO_PER 3            /* BrainPrioritizedReplyDQN: target net, mean(ISW * sq), abs_errors */
+
+int fb_qnet_create(int arch, int fc_width, int n_actions, int max_batch, fb_qnet_t *out);
+int fb_qnet_destroy(fb_qnet_t h);
+int fb_qnet_num_params(fb_qnet_t h, int64_t *n_host);
+/* tf.truncated_normal(stddev=0.01) weights, 0.01 biases, for `which` net. */
+int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *stream);
+int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat /*[dev]*/, void *stream);
+int fb_qnet_store_params(fb_qnet_t h, int which, float *flat /*[dev]*/, void *stream);
+/* Adam slots m, v (f32[n] [dev]) and beta powers ([host] f32[2]); synchronous. */
+int fb_qnet_get_adam_state(fb_qnet_t h, float *m, float *v, float *beta_pows_host);
+int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *v, const float *beta_pows_host);
+int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float eps);
+/* QValue.eval: states u8[B,80,80,4] -> q f32[B,A] */
+int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream);
+/* getAction for N envs: forward + epsilon-greedy (Philox stream 1, counter = step).
+ *   epsilon f32 by value; actions u8[N] out; q f32[N,A] out or NULL */
+int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsilon, uint64_t seed, uint64_t step,
+                uint8_t *actions, float *q, void *stream);
+/* One _trainQNetwork step on a gathered minibatch.
+ *   isw f32[B] (PER) or NULL; loss f32[1]; abs_err f32[B] or NULL; q_target f32[B] or NULL (all [dev])
+ *   flat_grad NULL : gradients are applied with Adam at once (single GPU)
+ *   flat_grad [dev] f32[n_params]: gradients are only written there (data parallel: all-reduce
+ *             them, then fb_qnet_apply_adam) */
+int fb_qnet_train_step(fb_qnet_t h, int algo, int batch, const uint8_t *s, const uint8_t *a, const float *r,
+                       const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
+                       float *abs_err, float *q_target, float *flat_grad, void *stream);
+int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream);
+int fb_qnet_sync_target(fb_qnet_t h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
