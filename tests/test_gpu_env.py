@@ -52,6 +52,7 @@ def test_reference_trajectories_all_tapes_in_one_launch(torch_cuda, golden, orac
     for i, n in enumerate(TAPES):
         assert np.array_equal(dev_state_to_snapshot(env.get_state()[i]), g[n + "_state"][0][:16])
     alive = [True] * len(TAPES)
+    cursor_at_end = {}
     frame_checks = 0
     for t in range(T):
         acts = np.zeros(len(TAPES), np.uint8)
@@ -72,6 +73,8 @@ def test_reference_trajectories_all_tapes_in_one_launch(torch_cuda, golden, orac
             assert score[i] == g[n + "_score"][t], (n, t)
             assert np.array_equal(dev_state_to_snapshot(st[i]), g[n + "_state"][t + 1][:16]), (n, t)
             orc[i].step(int(acts[i]))
+            if t == len(g[n + "_action"]) - 1:
+                cursor_at_end[i] = st[i, 15]
             if fr is not None:
                 want = orc[i].frame80()
                 assert np.array_equal(fr[i], want), (n, t, np.argwhere(fr[i] != want)[:5])
@@ -80,7 +83,7 @@ def test_reference_trajectories_all_tapes_in_one_launch(torch_cuda, golden, orac
                 frame_checks += 1
     assert frame_checks > 1000
     for i, n in enumerate(TAPES):
-        assert env.get_state()[i, 15] == len(g[n + "_draws"])
+        assert cursor_at_end[i] == len(g[n + "_draws"])      # every recorded draw consumed, none invented
 
 
 def test_philox_envs_match_oracle_1024(torch_cuda, oracle):
