@@ -1,0 +1,651 @@
+// fb_replay.hip -- replay memory in HBM (gfx950): frame ring, uniform + prioritized sampling, gather.
+//
+// Reference semantics (paths relative to the reference checkout):
+//   deque store / popleft      BrainDQN.py:36,69-72 (REPLAY_MEMORY = 50000, :26)
+//   frame stack                BrainDQN.py:68,238-239
+//   random.sample              BrainDQN.py:197      (CPython Lib/random.py, MT19937)
+//   minibatch assembly         BrainDQN.py:198-201  ("the replay gather")
+//   SumTree                    BrainPrioritizedReplyDQN.py:32-104
+//   Memory                     BrainPrioritizedReplyDQN.py:107-151
+//
+// Layout (DESIGN.md "Replay"):
+//   bits[T_f][N][100] u64   one 80x80 frame = 6400 bits (the preprocess only emits 0 / 255)
+//   act/rew/term[T_f][N]    per transition
+//   A vector step t pushes N transitions; transition (t, e) reads frames t-3..t (s) and t-2..t+1
+//   (s').  The reference's deque position j (0 = oldest) is g = oldest + j, (t, e) = divmod(g, N):
+//   with N = 1 this is exactly the reference's deque, with N > 1 it is the deque that N envs
+//   appending in env order would build.  T_f = ceil(cap / N) + 6 time slots keep every frame a
+//   live transition needs.
+//   PER: tree/maxt/mint f64[2*cap-1] array heaps.  `tree` is the reference's SumTree, updated with
+//   the same sequence of floating-point operations (so its bytes are the reference's bytes);
+//   maxt / mint replace the reference's O(capacity) np.max / min scans (max and min are exact and
+//   order independent, so they give the identical value).
+#include <math.h>
+#include "fb_common.h"
+
+namespace {
+
+constexpr int WORDS = 100;           // u64 words per frame
+constexpr int MAXB = 256;            // largest minibatch the single-workgroup sampler kernels take
+constexpr int MAXH = 23;             // tree depths handled (capacity < 2^22)
+
+struct ReplayDev {                   // mutable state, device resident (graph replay safe)
+    long long steps;                 // vector pushes so far
+    long long per_pointer, per_size; // SumTree.data_pointer / size
+    double beta;                     // Memory.beta
+    unsigned int done_ctr;           // last-block-done counter of the push kernel
+    unsigned int philox_calls;
+    int error;                       // sticky: bad index / batch larger than memory
+};
+
+struct ReplayParams {
+    long long cap;
+    int n_envs, t_f, kind;
+    unsigned long long *bits;
+    uint8_t *act; float *rew; uint8_t *term;
+    ReplayDev *dev;
+    double *tree, *maxt, *mint;
+    FbMT *mt;
+    int rng_kind;
+    uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ size_t frame_off(const ReplayParams &P, long long f, int e) {
+    if (f < 0) f = 0;                                   // setInitState: the first frame four times
+    return ((size_t)(f % P.t_f) * P.n_envs + e) * WORDS;
+}
+
+// ------------------------------------------------------------------ store
+__global__ __launch_bounds__(64) void reset_kernel(ReplayParams P, const uint8_t *__restrict__ frames,
+                                                   const unsigned long long *__restrict__ fbits) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    unsigned long long *dst = P.bits + frame_off(P, 0, e);
+    if (fbits) {
+        for (int w = lane; w < WORDS; w += 64) dst[w] = fbits[(size_t)e * WORDS + w];
+    } else {
+        for (int w = 0; w < WORDS; w++) {
+            const unsigned long long m = __ballot(frames[(size_t)e * 6400 + w * 64 + lane] != 0);
+            if (lane == 0) dst[w] = m;
+        }
+    }
+    if (e == 0 && lane == 0) {
+        P.dev->steps = 0; P.dev->per_pointer = 0; P.dev->per_size = 0; P.dev->beta = 0.4;
+        P.dev->done_ctr = 0; P.dev->error = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void push_kernel(ReplayParams P, const uint8_t *__restrict__ frames,
+                                                  const unsigned long long *__restrict__ fbits,
+                                                  const uint8_t *__restrict__ a, const float *__restrict__ r,
+                                                  const uint8_t *__restrict__ t) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const long long steps = P.dev->steps;               // transition index this push writes
+    unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
+    if (fbits) {
+        for (int w = lane; w < WORDS; w += 64) dst[w] = fbits[(size_t)e * WORDS + w];
+    } else {
+        for (int w = 0; w < WORDS; w++) {
+            const unsigned long long m = __ballot(frames[(size_t)e * 6400 + w * 64 + lane] != 0);
+            if (lane == 0) dst[w] = m;
+        }
+    }
+    if (lane == 0) {
+        const size_t mo = (size_t)(steps % P.t_f) * P.n_envs + e;
+        P.act[mo] = a[e]; P.rew[mo] = r[e]; P.term[mo] = t[e];
+        // the last workgroup to get here publishes the step (every workgroup read `steps` above)
+        __threadfence();
+        const unsigned int prev = atomicAdd(&P.dev->done_ctr, 1u);
+        if (prev == gridDim.x - 1) { P.dev->done_ctr = 0; P.dev->steps = steps + 1; }
+    }
+}
+
+// ------------------------------------------------------------------ gather (minibatch assembly)
+// One thread expands 4 pixels x 4 stacked frames = 16 contiguous bytes of s (and of s').
+__device__ __forceinline__ uint32_t expand4(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, int q) {
+    return (((n0 >> q) & 1u) * 0xFFu) | (((n1 >> q) & 1u) * 0xFF00u) | (((n2 >> q) & 1u) * 0xFF0000u) |
+           (((n3 >> q) & 1u) * 0xFF000000u);
+}
+
+template <bool CURRENT>
+__global__ __launch_bounds__(256) void gather_kernel(ReplayParams P, int B, const long long *__restrict__ idx,
+                                                     uint4 *__restrict__ s, uint4 *__restrict__ s2,
+                                                     uint8_t *__restrict__ a, float *__restrict__ r,
+                                                     uint8_t *__restrict__ t) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= (long long)B * 1600) return;
+    const int b = (int)(tid / 1600), chunk = (int)(tid - (long long)b * 1600);
+    const long long steps = P.dev->steps;
+    long long tt; int e;
+    if (CURRENT) { tt = steps; e = b; }
+    else {
+        const long long total = steps * P.n_envs;
+        long long g;
+        if (P.kind == FB_REPLAY_PER) {
+            long long d = idx[b] - (P.cap - 1);
+            if (d < 0 || d >= P.cap || d >= total) { if (chunk == 0) P.dev->error = 1; d = 0; }
+            g = d + P.cap * ((total - 1 - d) / P.cap);  // newest transition living in data slot d
+        } else {
+            const long long size = total < P.cap ? total : P.cap;
+            long long j = idx[b];
+            if (j < 0 || j >= size) { if (chunk == 0) P.dev->error = 1; j = 0; }
+            g = total - size + j;                       // deque position j, 0 = oldest
+        }
+        tt = g / P.n_envs; e = (int)(g - tt * P.n_envs);
+    }
+    const int p = chunk * 4, w = p >> 6, sh = p & 63;
+    uint32_t n[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (CURRENT && k == 4) { n[k] = 0; break; }
+        n[k] = (uint32_t)(P.bits[frame_off(P, tt - 3 + k, e) + w] >> sh) & 0xFu;
+    }
+    uint4 o;
+    o.x = expand4(n[0], n[1], n[2], n[3], 0); o.y = expand4(n[0], n[1], n[2], n[3], 1);
+    o.z = expand4(n[0], n[1], n[2], n[3], 2); o.w = expand4(n[0], n[1], n[2], n[3], 3);
+    s[tid] = o;
+    if (!CURRENT) {
+        o.x = expand4(n[1], n[2], n[3], n[4], 0); o.y = expand4(n[1], n[2], n[3], n[4], 1);
+        o.z = expand4(n[1], n[2], n[3], n[4], 2); o.w = expand4(n[1], n[2], n[3], n[4], 3);
+        s2[tid] = o;
+        if (chunk == 0) {
+            const size_t mo = (size_t)(tt % P.t_f) * P.n_envs + e;
+            a[b] = P.act[mo]; r[b] = P.rew[mo]; t[b] = P.term[mo];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ MT19937 on one wave
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+
+// Regenerate the 624-word block with 64 lanes.  Chunks go in increasing order; inside a chunk every
+// lane reads before any lane writes, which preserves the sequential algorithm's dependencies
+// (new values are needed at distance 227 behind, old values at distance 1 ahead).
+__device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
+    for (int base = 0; base < 624; base += 64) {
+        const int i = base + lane;
+        uint32_t v = 0;
+        if (i < 624) {
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[i == 623 ? 0 : i + 1] & 0x7fffffffu);
+            v = mt[i + 397 < 624 ? i + 397 : i + 397 - 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i < 624) mt[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// random.sample(range(n), k) on one wave; every lane runs the same control flow, lane (i & 63)
+// keeps result i in register slot i >> 6.
+__global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
+                                                            long long *__restrict__ out) {
+    __shared__ uint32_t mt[624];
+    __shared__ int pool[1100];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
+    uint32_t idx = P.mt->idx;
+    const long long total = P.dev->steps * P.n_envs;
+    const long long n = total < P.cap ? total : P.cap;
+    if (k > n || k > MAXB) {
+        if (lane == 0) P.dev->error = 2;                // "Sample larger than population"
+        for (int i = lane; i < k; i += 64) out[i] = 0;
+        return;
+    }
+    __syncthreads();
+    long long sel[4] = {-1, -1, -1, -1};
+    const bool use_pool = n <= setsize;
+    if (use_pool) { for (int i = lane; i < (int)n; i += 64) pool[i] = i; }
+    __syncthreads();
+    for (int i = 0; i < k; i++) {
+        const uint32_t m = use_pool ? (uint32_t)(n - i) : (uint32_t)n;
+        const int nbits = 32 - __builtin_clz(m);
+        uint32_t r;
+        for (;;) {                                      // _randbelow_with_getrandbits (+ the `in selected` retry)
+            if (idx >= 624) { mt_regen(mt, lane); idx = 0; }
+            r = mt_temper(mt[idx++]) >> (32 - nbits);
+            if (r >= m) continue;
+            if (use_pool) break;
+            bool dup = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) dup |= (sel[q] == (long long)r);
+            if (!__any(dup)) break;
+        }
+        long long res = r;
+        if (use_pool) {
+            res = pool[r];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) pool[r] = pool[m - 1];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == (i & 63)) sel[i >> 6] = res;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
+    for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];
+    if (lane == 0) P.mt->idx = idx;
+}
+
+__global__ void sample_philox_kernel(ReplayParams P, int k, long long *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = P.dev->steps * P.n_envs;
+    const long long n = total < P.cap ? total : P.cap;
+    const unsigned int call = P.dev->philox_calls;
+    if (i < k) {
+        const fb_u4 o = fb_philox(P.seed_lo, P.seed_hi, (uint32_t)i, call, FB_STREAM_SAMPLE, 0u);
+        out[i] = n > 0 ? (long long)(((unsigned long long)o.x * (unsigned long long)n) >> 32) : 0;
+    }
+    __syncthreads();
+    if (i == 0) { P.dev->philox_calls = call + 1; if (n <= 0) P.dev->error = 2; }
+}
+
+// ------------------------------------------------------------------ prioritized replay
+__global__ void fill_f64_kernel(double *p, long long n, double v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__device__ __forceinline__ int node_depth(long long node) {          // root = 0
+    return 63 - __builtin_clzll((unsigned long long)(node + 1));
+}
+// ancestor of leaf ti (depth D) at depth d <= D
+__device__ __forceinline__ long long anc(long long ti, int D, int d) { return ((ti + 1) >> (D - d)) - 1; }
+
+// Exact SumTree.update for a list of (tree_idx, p) applied IN ORDER (BrainPrioritizedReplyDQN.py:62-68),
+// on one wave: lane d owns the nodes at depth d.  The values of all touched nodes are first loaded
+// side by side (no dependent global latency), then the wave walks the list in lockstep:
+// change_j = p_j - leaf_j (the leaf's lane), every lane above adds change_j to its ancestor.  A node
+// touched by several list entries takes the value its previous occurrence left (prev[][]), which is
+// exactly the read-modify-write order of the reference's loop -- so the tree bytes are the reference's.
+// MONOTONE: the caller guarantees consecutive leaves of one depth without ring wrap (Memory.store),
+// so equal nodes are adjacent in the list and the duplicate search is one comparison.
+struct UpdScratch {
+    double val[MAXB][MAXH];          // value of node (j, depth) after step j
+    short prev[MAXB][MAXH];          // latest j' < j with the same node at that depth, or -1
+    long long ti[MAXB];
+    double p[MAXB];
+};
+
+template <bool MONOTONE>
+__device__ void per_apply_updates(const ReplayParams &P, UpdScratch &S, int n, int tid, int nthreads) {
+    // 1) preload + duplicate links, all threads
+    for (int it = tid; it < n * MAXH; it += nthreads) {
+        const int j = it / MAXH, d = it - j * MAXH;
+        const long long ti = S.ti[j];
+        const int D = node_depth(ti);
+        short pv = -1;
+        double v = 0;
+        if (d <= D) {
+            const long long node = anc(ti, D, d);
+            if (MONOTONE) {
+                if (j > 0) { const int Dq = node_depth(S.ti[j - 1]); if (d <= Dq && anc(S.ti[j - 1], Dq, d) == node) pv = (short)(j - 1); }
+            } else {
+                for (int q = j - 1; q >= 0; q--) {
+                    const int Dq = node_depth(S.ti[q]);
+                    if (d <= Dq && anc(S.ti[q], Dq, d) == node) { pv = (short)q; break; }
+                }
+            }
+            if (pv < 0) v = P.tree[node];
+        }
+        S.val[j][d] = v; S.prev[j][d] = pv;
+    }
+    __syncthreads();
+    // 2) the ordered walk, first wave only
+    if (tid < 64) {
+        const int d = tid;
+        for (int j = 0; j < n; j++) {
+            const int D = node_depth(S.ti[j]);
+            double change = 0;
+            if (d == D) {
+                const short pv = S.prev[j][d];
+                const double old = pv >= 0 ? S.val[pv][d] : S.val[j][d];
+                change = S.p[j] - old;                           // :63
+                S.val[j][d] = S.p[j];                            // :64
+            }
+            change = __shfl(change, D);
+            if (d < D) {
+                const short pv = S.prev[j][d];
+                const double old = pv >= 0 ? S.val[pv][d] : S.val[j][d];
+                S.val[j][d] = old + change;                      // :66-68
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // 3) write back: one depth per thread, list order, so the last occurrence of a node wins
+    for (int d = tid; d < MAXH; d += nthreads)
+        for (int j = 0; j < n; j++) {
+            const int D = node_depth(S.ti[j]);
+            if (d <= D) P.tree[anc(S.ti[j], D, d)] = S.val[j][d];
+        }
+    // 4) max / min heaps: leaves (last occurrence wins), then ancestors bottom-up
+    for (int j = tid; j < n; j += nthreads) {
+        bool last = true;
+        for (int q = j + 1; q < n; q++) if (S.ti[q] == S.ti[j]) { last = false; break; }
+        if (last) { P.maxt[S.ti[j]] = S.p[j]; P.mint[S.ti[j]] = S.p[j]; }
+    }
+    for (int d = MAXH - 2; d >= 0; d--) {
+        __threadfence_block();
+        __syncthreads();
+        for (int j = tid; j < n; j += nthreads) {
+            const int D = node_depth(S.ti[j]);
+            if (d < D) {
+                const long long node = anc(S.ti[j], D, d);
+                const double a = P.maxt[2 * node + 1], b = P.maxt[2 * node + 2];
+                const double c = P.mint[2 * node + 1], e = P.mint[2 * node + 2];
+                P.maxt[node] = a > b ? a : b;
+                P.mint[node] = c < e ? c : e;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// Memory.store for `count` new transitions (BrainPrioritizedReplyDQN.py:121-125, add :50-60)
+__global__ __launch_bounds__(256) void per_store_kernel(ReplayParams P, int count) {
+    extern __shared__ unsigned char smem[];
+    UpdScratch &S = *reinterpret_cast<UpdScratch *>(smem);
+    const int tid = threadIdx.x;
+    long long pointer = P.dev->per_pointer, size = P.dev->per_size;
+    // first data slot whose leaf sits on the deeper level (heap index >= 2^D - 1)
+    const int Dmax = node_depth(2 * P.cap - 2);
+    const long long deep0 = ((1ll << Dmax) - 1) - (P.cap - 1);   // may be <= 0: all leaves on one level
+    __syncthreads();
+    int done = 0;
+    while (done < count) {
+        long long n = count - done;
+        if (n > MAXB) n = MAXB;
+        if (n > P.cap - pointer) n = P.cap - pointer;             // do not cross the ring wrap
+        if (pointer < deep0 && pointer + n > deep0) n = deep0 - pointer;   // nor the leaf depth change
+        // np.max over all leaves: storing max_p never changes the maximum, re-read per chunk anyway
+        double max_p = P.maxt[0];
+        if (max_p == 0) max_p = 1.0;                             // abs_err_upper
+        for (int j = tid; j < (int)n; j += 256) {
+            S.ti[j] = pointer + j + P.cap - 1;
+            S.p[j] = max_p;
+        }
+        __syncthreads();
+        per_apply_updates<true>(P, S, (int)n, tid, 256);
+        pointer = (pointer + n) % P.cap;
+        size = size + n < P.cap ? size + n : P.cap;
+        done += (int)n;
+    }
+    if (tid == 0) { P.dev->per_pointer = pointer; P.dev->per_size = size; }
+}
+
+// Memory.batch_update (BrainPrioritizedReplyDQN.py:146-151)
+__global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, const long long *__restrict__ idx,
+                                                         float *__restrict__ abs_err,
+                                                         const float *__restrict__ prio) {
+    extern __shared__ unsigned char smem[];
+    UpdScratch &S = *reinterpret_cast<UpdScratch *>(smem);
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += 256) {
+        long long ti = idx[j];
+        if (ti < P.cap - 1 || ti > 2 * P.cap - 2) { P.dev->error = 1; ti = P.cap - 1; }
+        S.ti[j] = ti;
+        float ps;
+        if (prio) ps = prio[j];
+        else {
+            float e = abs_err[j] + 0.01f;                        // abs_errors += epsilon (in place, fp32)
+            abs_err[j] = e;
+            const float c = e < 1.0f ? e : 1.0f;                 // np.minimum(.., abs_err_upper)
+            ps = (float)pow((double)c, (double)0.6f);            // np.power(fp32, 0.6) -> fp32
+        }
+        S.p[j] = (double)ps;
+    }
+    __syncthreads();
+    per_apply_updates<false>(P, S, n, tid, 256);
+}
+
+// Memory.sample (BrainPrioritizedReplyDQN.py:127-144)
+__global__ __launch_bounds__(256) void per_sample_kernel(ReplayParams P, int n, const double *__restrict__ uni,
+                                                         long long *__restrict__ idx_out,
+                                                         double *__restrict__ isw_out) {
+    __shared__ uint32_t mt[624];
+    __shared__ uint32_t words[2 * MAXB];
+    const int tid = threadIdx.x;
+    const double old_beta = P.dev->beta;
+    const double nb = old_beta + 0.001;
+    const double beta = nb < 1.0 ? nb : 1.0;                     // np.min([1., beta + 0.001])
+    unsigned int call = P.dev->philox_calls;
+    if (!uni && P.rng_kind == FB_RNG_NUMPY) {                    // 2 words per np.random.uniform, in order
+        if (tid < 64) {
+            for (int i = tid; i < 624; i += 64) mt[i] = P.mt->mt[i];
+            uint32_t idx = P.mt->idx;
+            __builtin_amdgcn_wave_barrier();
+            int produced = 0;
+            while (produced < 2 * n) {
+                if (idx >= 624) { mt_regen(mt, tid); idx = 0; }
+                int avail = 624 - (int)idx, want = 2 * n - produced;
+                int take = avail < want ? avail : want;
+                for (int i = tid; i < take; i += 64) words[produced + i] = mt_temper(mt[idx + i]);
+                produced += take; idx += take;
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = tid; i < 624; i += 64) P.mt->mt[i] = mt[i];
+            if (tid == 0) P.mt->idx = idx;
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const double total = P.tree[0];
+        const double seg = total / n;                            // pri_seg
+        const double a = seg * tid, b = seg * (tid + 1);
+        double u;
+        if (uni) u = uni[tid];
+        else if (P.rng_kind == FB_RNG_NUMPY) {
+            const uint32_t x = words[2 * tid] >> 5, y = words[2 * tid + 1] >> 6;
+            u = (x * 67108864.0 + y) / 9007199254740992.0;
+        } else {
+            const fb_u4 o = fb_philox(P.seed_lo, P.seed_hi, (uint32_t)tid, call, FB_STREAM_PER, 0u);
+            u = ((o.x >> 5) * 67108864.0 + (o.y >> 6)) / 9007199254740992.0;
+        }
+        double v = a + (b - a) * u;                              // np.random.uniform(a, b)
+        const long long len = 2 * P.cap - 1;
+        long long parent = 0;
+        for (;;) {                                               // get_leaf, :85-100
+            const long long cl = 2 * parent + 1;
+            if (cl >= len) break;
+            const double left = P.tree[cl];
+            if (v <= left) parent = cl;
+            else { v -= left; parent = cl + 1; }
+        }
+        const double prob = P.tree[parent] / total;
+        const double min_prob = P.mint[0] / total;               // get_min_prob over the filled leaves
+        idx_out[tid] = parent;
+        isw_out[tid] = pow(prob / min_prob, -beta);
+    }
+    if (tid == 0) { P.dev->beta = beta; P.dev->philox_calls = call + 1; }
+}
+
+}  // namespace
+
+struct fb_replay {
+    ReplayParams P;
+    FbMT *h_mt;
+};
+
+extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out) {
+    FB_REQUIRE(out, "fb_replay_create: out is NULL");
+    FB_REQUIRE(capacity >= 1 && capacity < (1ll << 22), "fb_replay_create: capacity %lld out of range", (long long)capacity);
+    FB_REQUIRE(n_envs >= 1 && n_envs <= (1 << 22), "fb_replay_create: n_envs out of range");
+    FB_REQUIRE(kind == FB_REPLAY_UNIFORM || kind == FB_REPLAY_PER, "fb_replay_create: kind must be 0 or 1");
+    fb_replay *h = new fb_replay();
+    memset(h, 0, sizeof(*h));
+    ReplayParams &P = h->P;
+    P.cap = capacity; P.n_envs = n_envs; P.kind = kind;
+    P.t_f = (int)((capacity + n_envs - 1) / n_envs) + 6;
+    const size_t slots = (size_t)P.t_f * n_envs;
+    hipError_t e = hipMalloc(&P.bits, slots * WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&P.act, slots);
+    if (e == hipSuccess) e = hipMalloc(&P.rew, slots * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&P.term, slots);
+    if (e == hipSuccess) e = hipMalloc(&P.dev, sizeof(ReplayDev));
+    if (e == hipSuccess) e = hipMemset(P.dev, 0, sizeof(ReplayDev));
+    if (e == hipSuccess) e = hipMalloc(&P.mt, sizeof(FbMT));
+    if (e == hipSuccess && kind == FB_REPLAY_PER) {
+        const size_t nb = sizeof(double) * (size_t)(2 * capacity - 1);
+        e = hipMalloc(&P.tree, nb);
+        if (e == hipSuccess) e = hipMalloc(&P.maxt, nb);
+        if (e == hipSuccess) e = hipMalloc(&P.mint, nb);
+    }
+    if (e != hipSuccess) {
+        fb_set_error(e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP, "fb_replay_create: %s", hipGetErrorString(e));
+        fb_replay_destroy(h);
+        return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
+    }
+    *out = h;
+    int rc = fb_replay_seed(h, kind == FB_REPLAY_PER ? FB_RNG_NUMPY : FB_RNG_CPYTHON, 0);
+    if (rc != FB_OK) return rc;
+    return fb_replay_reset(h, nullptr, nullptr, nullptr);
+}
+
+extern "C" int fb_replay_destroy(fb_replay_t h) {
+    if (!h) return FB_OK;
+    ReplayParams &P = h->P;
+    void *ptrs[] = {P.bits, P.act, P.rew, P.term, P.dev, P.mt, P.tree, P.maxt, P.mint};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return FB_OK;
+}
+
+extern "C" int fb_replay_seed(fb_replay_t h, int rng_kind, uint64_t seed) {
+    FB_REQUIRE(h, "fb_replay_seed: NULL handle");
+    FB_REQUIRE(rng_kind >= 0 && rng_kind <= 2, "fb_replay_seed: rng_kind must be 0 (cpython), 1 (philox) or 2 (numpy)");
+    FbMT s;
+    if (rng_kind == FB_RNG_NUMPY) fb_mt_init_genrand_host(&s, (uint32_t)seed);       // np.random.seed(int)
+    else {                                                                           // random.seed(int)
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        fb_mt_init_by_array_host(&s, key, key[1] ? 2 : 1);
+    }
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    FB_CHECK_HIP(hipMemcpy(h->P.mt, &s, sizeof(FbMT), hipMemcpyHostToDevice));
+    h->P.rng_kind = rng_kind;
+    h->P.seed_lo = (uint32_t)seed; h->P.seed_hi = (uint32_t)(seed >> 32);
+    return FB_OK;
+}
+
+extern "C" int fb_replay_reset(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, void *stream) {
+    FB_REQUIRE(h, "fb_replay_reset: NULL handle");
+    ReplayParams &P = h->P;
+    hipStream_t st = fb_stream(stream);
+    if (P.kind == FB_REPLAY_PER) {
+        const long long nn = 2 * P.cap - 1;
+        FB_CHECK_HIP(hipMemsetAsync(P.tree, 0, sizeof(double) * nn, st));
+        FB_CHECK_HIP(hipMemsetAsync(P.maxt, 0, sizeof(double) * nn, st));
+        hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, P.mint, nn, (double)INFINITY);
+        FB_LAUNCH_CHECK();
+    }
+    if (!frames && !frame_bits) {       // create-time reset: empty memory, blank first frame
+        FB_CHECK_HIP(hipMemsetAsync(P.bits, 0, (size_t)P.n_envs * WORDS * sizeof(unsigned long long), st));
+        FB_CHECK_HIP(hipMemsetAsync(P.dev, 0, sizeof(ReplayDev), st));
+        ReplayDev d; memset(&d, 0, sizeof(d)); d.beta = 0.4;
+        FB_CHECK_HIP(hipStreamSynchronize(st));
+        FB_CHECK_HIP(hipMemcpy(P.dev, &d, sizeof(d), hipMemcpyHostToDevice));
+        return FB_OK;
+    }
+    hipLaunchKernelGGL(reset_kernel, dim3(P.n_envs), dim3(64), 0, st, P, frames, (const unsigned long long *)frame_bits);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
+                              const float *rewards, const uint8_t *terminals, void *stream) {
+    FB_REQUIRE(h && actions && rewards && terminals, "fb_replay_push: NULL argument");
+    FB_REQUIRE((frames != nullptr) != (frame_bits != nullptr), "fb_replay_push: give exactly one of frames / frame_bits");
+    ReplayParams &P = h->P;
+    hipStream_t st = fb_stream(stream);
+    hipLaunchKernelGGL(push_kernel, dim3(P.n_envs), dim3(64), 0, st, P, frames, (const unsigned long long *)frame_bits,
+                       actions, rewards, terminals);
+    FB_LAUNCH_CHECK();
+    if (P.kind == FB_REPLAY_PER) {
+        hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(256), sizeof(UpdScratch), st, P, P.n_envs);
+        FB_LAUNCH_CHECK();
+    }
+    return FB_OK;
+}
+
+extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream) {
+    FB_REQUIRE(h && states, "fb_replay_current_state: NULL argument");
+    ReplayParams &P = h->P;
+    const long long threads = (long long)P.n_envs * 1600;
+    hipLaunchKernelGGL(gather_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, fb_stream(stream), P,
+                       P.n_envs, (const long long *)nullptr, (uint4 *)states, (uint4 *)nullptr, (uint8_t *)nullptr,
+                       (float *)nullptr, (uint8_t *)nullptr);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, void *stream) {
+    FB_REQUIRE(h && idx, "fb_replay_sample: NULL argument");
+    FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_sample: batch must be in 1..%d", MAXB);
+    ReplayParams &P = h->P;
+    hipStream_t st = fb_stream(stream);
+    if (P.kind == FB_REPLAY_PER) {
+        FB_REQUIRE(isw, "fb_replay_sample: PER needs isw");
+        hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, st, P, batch, uniforms, (long long *)idx, isw);
+    } else if (P.rng_kind == FB_RNG_PHILOX) {
+        hipLaunchKernelGGL(sample_philox_kernel, dim3(1), dim3(256), 0, st, P, batch, (long long *)idx);
+    } else {
+        // Lib/random.py: setsize = 21; if k > 5: setsize += 4 ** _ceil(_log(k * 3, 4))
+        long long setsize = 21;
+        if (batch > 5) setsize += (long long)pow(4.0, ceil(log((double)batch * 3.0) / log(4.0)));
+        hipLaunchKernelGGL(sample_cpython_kernel, dim3(1), dim3(64), 0, st, P, batch, setsize, (long long *)idx);
+    }
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r,
+                                uint8_t *t, void *stream) {
+    FB_REQUIRE(h && idx && s && s2 && a && r && t, "fb_replay_gather: NULL argument");
+    FB_REQUIRE(batch >= 1 && batch <= (1 << 20), "fb_replay_gather: batch out of range");
+    const long long threads = (long long)batch * 1600;
+    hipLaunchKernelGGL(gather_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, fb_stream(stream), h->P,
+                       batch, (const long long *)idx, (uint4 *)s, (uint4 *)s2, a, r, t);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err,
+                                           const float *priorities_or_null, void *stream) {
+    FB_REQUIRE(h && idx && (abs_err || priorities_or_null), "fb_replay_update_priorities: NULL argument");
+    FB_REQUIRE(h->P.kind == FB_REPLAY_PER, "fb_replay_update_priorities: not a prioritized memory");
+    FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_update_priorities: batch must be in 1..%d", MAXB);
+    hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), sizeof(UpdScratch), fb_stream(stream), h->P, batch,
+                       (const long long *)idx, abs_err, priorities_or_null);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_replay_size(fb_replay_t h, int64_t *size_host) {
+    FB_REQUIRE(h && size_host, "fb_replay_size: NULL argument");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    ReplayDev d;
+    FB_CHECK_HIP(hipMemcpy(&d, h->P.dev, sizeof(d), hipMemcpyDeviceToHost));
+    if (d.error) {
+        const int code = d.error;
+        d.error = 0;
+        FB_CHECK_HIP(hipMemcpy(h->P.dev, &d, sizeof(d), hipMemcpyHostToDevice));
+        return fb_set_error(code == 2 ? FB_ERR_STATE : FB_ERR_INVALID,
+                            code == 2 ? "replay: Sample larger than population or is negative"
+                                      : "replay: an index handed to gather/update was out of range");
+    }
+    const long long total = d.steps * h->P.n_envs;
+    *size_host = total < h->P.cap ? total : h->P.cap;
+    return FB_OK;
+}
+
+extern "C" int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *data_pointer, int64_t *size, double *beta) {
+    FB_REQUIRE(h && h->P.kind == FB_REPLAY_PER, "fb_replay_per_tree: not a prioritized memory");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    ReplayDev d;
+    FB_CHECK_HIP(hipMemcpy(&d, h->P.dev, sizeof(d), hipMemcpyDeviceToHost));
+    if (tree_host) FB_CHECK_HIP(hipMemcpy(tree_host, h->P.tree, sizeof(double) * (size_t)(2 * h->P.cap - 1), hipMemcpyDeviceToHost));
+    if (data_pointer) *data_pointer = d.per_pointer;
+    if (size) *size = d.per_size;
+    if (beta) *beta = d.beta;
+    return FB_OK;
+}

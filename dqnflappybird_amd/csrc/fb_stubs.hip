@@ -1,16 +1,5 @@
 // fb_stubs.hip -- TEMPORARY: entry points not implemented yet fail loudly.
 #include "fb_common.h"
-extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out) { return fb_set_error(FB_ERR_STATE, "fb_replay_create: not implemented yet"); }
-extern "C" int fb_replay_destroy(fb_replay_t h) { return fb_set_error(FB_ERR_STATE, "fb_replay_destroy: not implemented yet"); }
-extern "C" int fb_replay_seed(fb_replay_t h, int rng_kind, uint64_t seed) { return fb_set_error(FB_ERR_STATE, "fb_replay_seed: not implemented yet"); }
-extern "C" int fb_replay_reset(fb_replay_t h, const uint8_t *frames , const uint64_t *frame_bits , void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_reset: not implemented yet"); }
-extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions, const float *rewards, const uint8_t *terminals, void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_push: not implemented yet"); }
-extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_current_state: not implemented yet"); }
-extern "C" int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_sample: not implemented yet"); }
-extern "C" int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r, uint8_t *t, void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_gather: not implemented yet"); }
-extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err, const float *priorities_or_null, void *stream) { return fb_set_error(FB_ERR_STATE, "fb_replay_update_priorities: not implemented yet"); }
-extern "C" int fb_replay_size(fb_replay_t h, int64_t *size_host) { return fb_set_error(FB_ERR_STATE, "fb_replay_size: not implemented yet"); }
-extern "C" int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *data_pointer, int64_t *size, double *beta) { return fb_set_error(FB_ERR_STATE, "fb_replay_per_tree: not implemented yet"); }
 extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_batch, fb_qnet_t *out) { return fb_set_error(FB_ERR_STATE, "fb_qnet_create: not implemented yet"); }
 extern "C" int fb_qnet_destroy(fb_qnet_t h) { return fb_set_error(FB_ERR_STATE, "fb_qnet_destroy: not implemented yet"); }
 extern "C" int fb_qnet_num_params(fb_qnet_t h, int64_t *n_host) { return fb_set_error(FB_ERR_STATE, "fb_qnet_num_params: not implemented yet"); }

@@ -91,3 +91,97 @@ class VecGameState:
         v = C.c_int64()
         L.check(L.lib().fb_env_error_count(self.h, C.byref(v)), "fb_env_error_count")
         return v.value
+
+
+class VecReplay:
+    """Replay memory in HBM for N envs (BrainDQN.py:36,69-72,197-201;
+    BrainPrioritizedReplyDQN.py:32-151).  Frames are stored once, 1 bit per pixel."""
+
+    def __init__(self, capacity, n_envs=1, prioritized=False, device="cuda"):
+        L.require_gpu()
+        self.capacity, self.n, self.prioritized = int(capacity), int(n_envs), bool(prioritized)
+        self.device = torch.device(device)
+        self.h = C.c_void_p()
+        L.check(L.lib().fb_replay_create(self.capacity, self.n, L.REPLAY_PER if prioritized else L.REPLAY_UNIFORM,
+                                         C.byref(self.h)), "fb_replay_create")
+        self._buf = {}
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            L.lib().fb_replay_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def seed(self, seed, rng=None):
+        """rng: 'cpython' (random.seed), 'numpy' (np.random.seed) or 'philox'."""
+        kind = {"cpython": L.RNG_CPYTHON, "philox": L.RNG_PHILOX, "numpy": L.RNG_NUMPY}[
+            rng or ("numpy" if self.prioritized else "cpython")]
+        L.check(L.lib().fb_replay_seed(self.h, kind, seed), "fb_replay_seed")
+
+    @staticmethod
+    def _split(frames):
+        """u8[N,80,80] -> (frames, None); int64[N,100] packed bits -> (None, bits)."""
+        _dev_check(frames)
+        if frames.dtype == torch.uint8:
+            return frames, None
+        if frames.dtype == torch.int64:
+            return None, frames
+        raise ValueError("frames must be uint8[N,80,80] or int64[N,100] (packed)")
+
+    def reset(self, first_frames):
+        f, b = self._split(first_frames)
+        L.check(L.lib().fb_replay_reset(self.h, L.ptr(f), L.ptr(b), L.current_stream()), "fb_replay_reset")
+
+    def push(self, next_frames, actions, rewards, terminals):
+        f, b = self._split(next_frames)
+        _dev_check(actions, rewards, terminals)
+        L.check(L.lib().fb_replay_push(self.h, L.ptr(f), L.ptr(b), L.ptr(actions), L.ptr(rewards), L.ptr(terminals),
+                                       L.current_stream()), "fb_replay_push")
+
+    def _get(self, name, shape, dtype):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def current_state(self):
+        out = self._get("cur", (self.n, 80, 80, 4), torch.uint8)
+        L.check(L.lib().fb_replay_current_state(self.h, L.ptr(out), L.current_stream()), "fb_replay_current_state")
+        return out
+
+    def sample(self, batch, uniforms=None):
+        """-> idx int64[B] (deque positions, or SumTree indices for PER), isw float64[B] or None."""
+        idx = self._get(f"idx{batch}", (batch,), torch.int64)
+        isw = self._get(f"isw{batch}", (batch,), torch.float64) if self.prioritized else None
+        _dev_check(uniforms)
+        L.check(L.lib().fb_replay_sample(self.h, batch, L.ptr(uniforms), L.ptr(idx), L.ptr(isw), L.current_stream()),
+                "fb_replay_sample")
+        return idx, isw
+
+    def gather(self, idx):
+        B = idx.numel()
+        s = self._get(f"s{B}", (B, 80, 80, 4), torch.uint8)
+        s2 = self._get(f"s2{B}", (B, 80, 80, 4), torch.uint8)
+        a = self._get(f"a{B}", (B,), torch.uint8)
+        r = self._get(f"r{B}", (B,), torch.float32)
+        t = self._get(f"t{B}", (B,), torch.uint8)
+        L.check(L.lib().fb_replay_gather(self.h, B, L.ptr(idx), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r), L.ptr(t),
+                                         L.current_stream()), "fb_replay_gather")
+        return s, a, r, s2, t
+
+    def update_priorities(self, idx, abs_err=None, priorities=None):
+        _dev_check(idx, abs_err, priorities)
+        L.check(L.lib().fb_replay_update_priorities(self.h, idx.numel(), L.ptr(idx), L.ptr(abs_err), L.ptr(priorities),
+                                                    L.current_stream()), "fb_replay_update_priorities")
+
+    def __len__(self):
+        v = C.c_int64()
+        L.check(L.lib().fb_replay_size(self.h, C.byref(v)), "fb_replay_size")
+        return v.value
+
+    def per_state(self, want_tree=True):
+        tree = np.empty(2 * self.capacity - 1, np.float64) if want_tree else None
+        ptr_, size, beta = C.c_int64(), C.c_int64(), C.c_double()
+        L.check(L.lib().fb_replay_per_tree(self.h, L.ptr(tree), C.byref(ptr_), C.byref(size), C.byref(beta)),
+                "fb_replay_per_tree")
+        return tree, ptr_.value, size.value, beta.value

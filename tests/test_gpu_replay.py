@@ -1,0 +1,260 @@
+"""HIP replay memory (through the C ABI): deque semantics, bit-exact CPython sampling, gather,
+and the prioritized SumTree/Memory bit-exact against the reference's own classes."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def rand_frames(rng, n):
+    return (rng.random((n, 80, 80)) < 0.37).astype(np.uint8) * 255
+
+
+class DequeModel:
+    """The reference's replayMemory for N envs appending in env order (BrainDQN.py:66-72)."""
+
+    def __init__(self, cap, first):                  # first: u8[N,80,80]
+        self.cap = cap
+        self.state = np.stack([first] * 4, axis=-1)  # setInitState, BrainDQN.py:238-239
+        self.mem = []
+
+    def push(self, nxt, a, r, t):
+        new = np.concatenate([self.state[..., 1:], nxt[..., None]], axis=-1)   # BrainDQN.py:68
+        for e in range(len(a)):
+            self.mem.append((self.state[e], a[e], r[e], new[e], t[e]))
+            if len(self.mem) > self.cap:
+                self.mem.pop(0)
+        self.state = new
+
+
+@pytest.mark.parametrize("n_envs,cap,steps", [(1, 50, 130), (4, 50, 40), (3, 100, 80), (8, 1000, 200)])
+def test_uniform_deque_semantics_and_gather(torch_cuda, n_envs, cap, steps):
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    rng = np.random.default_rng(n_envs * 1000 + cap)
+    rep = VecReplay(cap, n_envs)
+    first = rand_frames(rng, n_envs)
+    rep.reset(torch.from_numpy(first).cuda())
+    model = DequeModel(cap, first)
+    assert len(rep) == 0
+    rep.seed(12345)
+    random.seed(12345)
+    for t in range(steps):
+        nxt = rand_frames(rng, n_envs)
+        a = rng.integers(0, 2, n_envs).astype(np.uint8)
+        r = rng.choice(np.array([0.1, 3, -3], np.float32), n_envs)
+        te = (r == -3).astype(np.uint8)
+        rep.push(torch.from_numpy(nxt).cuda(), torch.from_numpy(a).cuda(), torch.from_numpy(r).cuda(),
+                 torch.from_numpy(te).cuda())
+        model.push(nxt, a, r, te)
+        assert np.array_equal(rep.current_state().cpu().numpy(), model.state)
+        if len(model.mem) >= 32 and t % 3 == 0:
+            assert len(rep) == len(model.mem)
+            idx, _ = rep.sample(32)
+            want_idx = random.sample(range(len(model.mem)), 32)          # BrainDQN.py:197
+            assert idx.cpu().tolist() == want_idx
+            s, aa, rr, s2, tt = (x.cpu().numpy() for x in rep.gather(idx))
+            for b, j in enumerate(want_idx):
+                ms, ma, mr, ms2, mt = model.mem[j]
+                assert np.array_equal(s[b], ms) and np.array_equal(s2[b], ms2), (t, b, j)
+                assert (aa[b], rr[b], tt[b]) == (ma, mr, mt)
+
+
+def test_cpython_sample_golden_vectors(torch_cuda, golden):
+    """random.sample(range(n), k) for the fixture's (seed, n, k) incl. the pool path (n <= setsize)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    g = golden("cpython_random.npz")
+    z8 = torch.zeros((1, 80, 80), dtype=torch.uint8, device="cuda")
+    za, zr = torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.float32, device="cuda")
+    checked = 0
+    for key in sorted(g.files):
+        if not key.startswith("sample_"):
+            continue
+        _, s, n, k = key.split("_")
+        seed, n, k = int(s[1:]), int(n[1:]), int(k[1:])
+        if n > 2000:
+            continue                                  # those sizes run in the N-env test below
+        rep = VecReplay(n, 1)
+        rep.reset(z8)
+        for _ in range(n):
+            rep.push(z8, za, zr, za)
+        rep.seed(seed)
+        for want in g[key]:
+            idx, _ = rep.sample(k)
+            assert idx.cpu().tolist() == list(want), key
+        checked += 1
+    assert checked >= 16
+
+
+@pytest.mark.parametrize("n", [50000, 1000000])
+def test_cpython_sample_large_memories(torch_cuda, golden, n):
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    g = golden("cpython_random.npz")
+    N = 1000
+    rep = VecReplay(n, N)
+    z8 = torch.zeros((N, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    for _ in range(n // N):
+        rep.push(z8, za, zr, za)
+    assert len(rep) == n
+    for seed in (0, 1, 12345, 2 ** 40 + 7):
+        for k in (32, 256):
+            rep.seed(seed)
+            for want in g[f"sample_s{seed}_n{n}_k{k}"]:
+                idx, _ = rep.sample(k)
+                assert idx.cpu().tolist() == list(want)
+
+
+def test_sample_larger_than_population_fails_loudly(torch_cuda):
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    from dqnflappybird_amd._lib import FbError
+    rep = VecReplay(100, 1)
+    z8 = torch.zeros((1, 80, 80), dtype=torch.uint8, device="cuda")
+    za, zr = torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    for _ in range(10):
+        rep.push(z8, za, zr, za)
+    rep.sample(32)
+    with pytest.raises(FbError, match="Sample larger than population"):
+        len(rep)
+
+
+def test_philox_sampler_in_range_and_reproducible(torch_cuda):
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    N = 64
+    reps = [VecReplay(5000, N), VecReplay(5000, N)]
+    z8 = torch.zeros((N, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda")
+    out = []
+    for rep in reps:
+        rep.reset(z8)
+        for _ in range(50):
+            rep.push(z8, za, zr, za)
+        rep.seed(7, "philox")
+        out.append(torch.stack([rep.sample(256)[0].clone() for _ in range(20)]).cpu().numpy())
+    assert np.array_equal(out[0], out[1])
+    assert out[0].min() >= 0 and out[0].max() < 3200 and len(np.unique(out[0])) > 2500
+
+
+# ----------------------------------------------------------------------------- PER
+def per_replay_case(torch, golden, name, n_envs=1):
+    from dqnflappybird_amd.vec import VecReplay
+    g = golden("per_sumtree.npz")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "per_sumtree.json")) as f:
+        meta = json.load(f)[name]
+    cap, n = meta["capacity"], meta["n"]
+    rep = VecReplay(cap, n_envs, prioritized=True)
+    z8 = torch.zeros((n_envs, 100), dtype=torch.int64, device="cuda")
+    za = torch.zeros(n_envs, dtype=torch.uint8, device="cuda")
+    zr = torch.zeros(n_envs, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    rep.seed(meta["seed"], "numpy")
+    rnd = 0
+    for kind, k in meta["ops"]:
+        if kind == "store":
+            assert k % n_envs == 0
+            for _ in range(k // n_envs):
+                rep.push(z8, za, zr, za)
+        else:
+            idx, isw = rep.sample(n)
+            assert idx.cpu().tolist() == list(g[name + "_b_idx"][rnd]), (name, rnd)
+            np.testing.assert_allclose(isw.cpu().numpy(), g[name + "_isw"][rnd], rtol=1e-13)
+            rep.update_priorities(idx, priorities=torch.from_numpy(g[name + "_ps"][rnd]).cuda())
+            rnd += 1
+    assert rnd == meta["rounds"]
+    tree, ptr, size, beta = rep.per_state()
+    assert (ptr, size) == (meta["data_pointer"], meta["size"])
+    assert beta == g[name + "_beta"][-1]
+    return tree, g, meta
+
+
+@pytest.mark.parametrize("name", ["cap8", "cap50", "cap1000"])
+def test_per_bit_exact_small(torch_cuda, golden, name):
+    tree, g, meta = per_replay_case(torch_cuda, golden, name)
+    assert np.array_equal(tree.view(np.uint64), g[name + "_tree"].view(np.uint64))
+
+
+def test_per_bit_exact_reference_capacity(torch_cuda, golden):
+    """capacity 50 000 (REPLAY_MEMORY): two leaf levels, ring wrap, 53 sample/update rounds."""
+    name = "cap50000"
+    tree, g, meta = per_replay_case(torch_cuda, golden, name)
+    assert np.array_equal(tree[:1023].view(np.uint64), g[name + "_tree_top"].view(np.uint64))
+    assert np.array_equal(tree[::97].view(np.uint64), g[name + "_tree_stride97"].view(np.uint64))
+    x = np.bitwise_xor.reduce(tree.view(np.uint64) * (np.arange(tree.size, dtype=np.uint64) | np.uint64(1)))
+    assert x == g[name + "_tree_xor"][0]
+
+
+def test_per_vector_store_equals_sequential(torch_cuda, golden):
+    """N envs storing per step == the same transitions stored one by one (997 = 997 x 1 here,
+    cap50000 tape with n_envs = 997)."""
+    name = "cap50000"
+    g = golden("per_sumtree.npz")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "per_sumtree.json")) as f:
+        meta = json.load(f)[name]
+    # the tape's warm-up store count (40) is not a multiple of 997: replay it with n_envs = 1 first
+    # is covered above; here check pure stores with N = 997 against the oracle
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    from oracle import oracle as o
+    N, cap = 997, 50000
+    rep = VecReplay(cap, N, prioritized=True)
+    z8 = torch.zeros((N, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    mem = o.Memory(cap)
+    rng = np.random.default_rng(5)
+    for step in range(60):                       # 59 820 stores: wraps the ring and crosses the level split
+        rep.push(z8, za, zr, za)
+        mem.store(N)
+        if step % 7 == 3:
+            u = rng.random(32)
+            idx, isw = rep.sample(32, uniforms=torch.from_numpy(u).cuda())
+            oi, ow = mem.sample(32, u=u)
+            assert idx.cpu().tolist() == list(oi)
+            np.testing.assert_allclose(isw.cpu().numpy(), ow, rtol=1e-13)
+            ps = (rng.random(32).astype(np.float32) * 1.2 + 0.01).clip(max=1.0) ** np.float32(0.6)
+            rep.update_priorities(idx, priorities=torch.from_numpy(ps).cuda())
+            mem.batch_update_p(oi, ps)
+    tree, ptr, size, beta = rep.per_state()
+    assert (ptr, size) == (mem.data_pointer, mem.size)
+    assert np.array_equal(tree.view(np.uint64), mem.tree.view(np.uint64))
+
+
+def test_per_device_pow_close_to_numpy(torch_cuda, golden):
+    """abs_err path: (min(|e|+0.01, 1))^0.6 computed on the device, within 1 fp32 ulp of NumPy's
+    (which itself is not correctly rounded), and abs_err updated in place like the reference."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    g = golden("per_sumtree.npz")
+    e = g["cap1000_abs_err"].reshape(-1)[:256].copy()
+    want = g["cap1000_ps"].reshape(-1)[:256]
+    rep = VecReplay(256, 1, prioritized=True)
+    z8 = torch.zeros((1, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    for _ in range(256):
+        rep.push(z8, za, zr, za)
+    idx = torch.arange(255, 511, dtype=torch.int64, device="cuda")
+    ed = torch.from_numpy(e).cuda()
+    rep.update_priorities(idx, abs_err=ed)
+    np.testing.assert_array_equal(ed.cpu().numpy(), e + np.float32(0.01))
+    tree, _, _, _ = rep.per_state()
+    got = tree[255:].astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
