@@ -1,0 +1,829 @@
+// fb_qnet.hip -- the DQN Q-network, its losses, backward pass and TF-style Adam on gfx950.
+//
+// Reference semantics (paths relative to the reference checkout):
+//   network        BrainDQN.py:119-155  conv 8x8/4 SAME + relu -> max_pool 2x2/2 -> conv 4x4/2 SAME + relu
+//                                       -> conv 3x3/1 SAME + relu -> NHWC flatten -> fc 1600xFC + relu -> fc FCxA
+//   dueling head   BrainDuelingDQN.py:78-86
+//   getAction      BrainDQN.py:99-116
+//   targets/loss   BrainDQN.py:159-162,210-215; BrainDQNNature.py:118-119,164-175;
+//                  BrainDoubleDQN.py:51-61; BrainPrioritizedReplyDQN.py:247-251
+//   optimizer      BrainDQN.py:163 -> TF ApplyAdam (m += (g-m)(1-b1); v += (g*g-v)(1-b2);
+//                  var -= m*alpha/(sqrt(v)+eps); alpha = lr*sqrt(1-b2^t)/(1-b1^t))
+//
+// Every layer is an implicit GEMM on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32
+// (exact fp32 FMA chain, same rate as the vector ALU but one wave per SIMD saturates it, which is
+// what a batch of 32 needs).  One workgroup owns one 32x32 output tile; its waves split the
+// reduction dimension and are summed through LDS in a fixed order, so every result is bit
+// reproducible (no atomics anywhere).  DESIGN.md "Q-network kernels" has the tile tables.
+#include <math.h>
+#include "fb_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int OFF_W1 = 0, OFF_B1 = 8192, OFF_W2 = 8224, OFF_B2 = 40992, OFF_W3 = 41056, OFF_B3 = 77920,
+              OFF_WF1 = 77984;
+constexpr int CONV_PARAMS = OFF_WF1;         // everything in front of W_fc1
+constexpr int MAXA = 8, MAXTB = 256;
+
+struct NetOff { int bf1, wv, bv, wq, bq, n; };
+
+struct Slice { const float *params; const uint8_t *states; int s_off, count; };
+struct Slices { Slice s[3]; };
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// D layout of the 32x32 tile: lane -> column (lane & 31), register r -> row
+__device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int NW>
+__device__ __forceinline__ void reduce_waves(f32x16 &acc, float *red, int wave, int lane) {
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < NW; w++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
+        }
+    }
+}
+
+// KH MFMAs: A from a contiguous run of KH floats (or zeros), B from a column with stride bstride
+template <int KH>
+__device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
+                                            int bstride, f32x16 &acc) {
+    float a[KH], b[KH];
+#pragma unroll
+    for (int q = 0; q < KH / 4; q++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < KH; t++) b[t] = bcol[(size_t)t * bstride];
+#pragma unroll
+    for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
+}
+
+// KH MFMAs with both operands as contiguous runs
+template <int KH>
+__device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool ok, const float *__restrict__ brun,
+                                            f32x16 &acc) {
+    float a[KH], b[KH];
+#pragma unroll
+    for (int q = 0; q < KH / 4; q++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        const float4 u = reinterpret_cast<const float4 *>(brun)[q];
+        b[4 * q] = u.x; b[4 * q + 1] = u.y; b[4 * q + 2] = u.z; b[4 * q + 3] = u.w;
+    }
+#pragma unroll
+    for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
+}
+
+// ================================================================== forward
+// conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2.  Tile rows = 8 pooled pixels x 4
+// window positions, so the pool is a max over 4 accumulator registers of one lane.
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
+    __shared__ float red[3 * 16 * 64];
+    const Slice s = sl.s[blockIdx.z];
+    const int npool = s.count * 100, tile = blockIdx.x;
+    if (tile * 8 >= npool) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int ky = 2 * wave + hl;
+    const int P = tile * 8 + (i >> 2), pos = i & 3;
+    const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
+    const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+    const int iy = oy * 4 + ky - 2;
+    const bool rowok = P < npool && iy >= 0 && iy < 80;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(s.states) + ((size_t)b * 80 + (rowok ? iy : 0)) * 80;
+    float a[32];
+#pragma unroll
+    for (int kx = 0; kx < 8; kx++) {
+        const int ix = ox * 4 + kx - 2;
+        uint32_t v = 0;
+        if (rowok && ix >= 0 && ix < 80) v = src[ix];
+        a[4 * kx] = (float)(v & 255u); a[4 * kx + 1] = (float)((v >> 8) & 255u);
+        a[4 * kx + 2] = (float)((v >> 16) & 255u); a[4 * kx + 3] = (float)(v >> 24);
+    }
+    const float *W = s.params + OFF_W1 + (ky * 32) * 32 + j;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int t = 0; t < 32; t++) acc = mfma(a[t], W[t * 32], acc);
+    reduce_waves<4>(acc, red, wave, lane);
+    if (wave == 0) {
+        const float bias = s.params[OFF_B1 + j];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float bv = fmaxf(acc[4 * g] + bias, 0.f);
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; q++) {
+                const float v = fmaxf(acc[4 * g + q] + bias, 0.f);
+                if (v > bv) { bv = v; best = q; }
+            }
+            const int Pp = tile * 8 + 2 * g + hl;
+            if (Pp < npool) {
+                const size_t o = ((size_t)s.s_off * 100 + Pp) * 32 + j;
+                p1[o] = bv; amax[o] = (uint8_t)best;
+            }
+        }
+    }
+}
+
+// conv2 4x4x32->64 stride 2 SAME(1,1) + bias + relu; 8 waves = 16 kernel cells / 2
+__global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
+    __shared__ float red[7 * 16 * 64];
+    const Slice s = sl.s[blockIdx.z];
+    const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int ky = wave >> 1, kx = 2 * (wave & 1) + hl;
+    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
+    const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+    const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
+    const float *arun = p1 + (((size_t)(s.s_off + b) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
+    const float *bcol = s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j;
+    f32x16 acc = {0};
+    mma_run_col<32>(arun, ok, bcol, 64, acc);
+    reduce_waves<8>(acc, red, wave, lane);
+    if (wave == 0) {
+        const float bias = s.params[OFF_B2 + n0 + j];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = tile * 32 + drow(r, lane);
+            if (mr < M) h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+        }
+    }
+}
+
+// conv3 3x3x64->64 stride 1 SAME(1,1) + bias + relu; 9 waves = 9 kernel cells
+__global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
+    __shared__ float red[8 * 16 * 64];
+    const Slice s = sl.s[blockIdx.z];
+    const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int ky = wave / 3, kx = wave - ky * 3;
+    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
+    const int iy = oy + ky - 1, ix = ox + kx - 1;
+    const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
+    const float *arun = h2 + ((size_t)(s.s_off + b) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
+    const float *bcol = s.params + OFF_W3 + ((size_t)(wave * 64) + 32 * hl) * 64 + n0 + j;
+    f32x16 acc = {0};
+    mma_run_col<32>(arun, ok, bcol, 64, acc);
+    reduce_waves<9>(acc, red, wave, lane);
+    if (wave == 0) {
+        const float bias = s.params[OFF_B3 + n0 + j];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = tile * 32 + drow(r, lane);
+            if (mr < M) h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+        }
+    }
+}
+
+// fc1 1600xFC + bias + relu; 8 waves x 200 k
+__global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hf, int FC) {
+    __shared__ float red[7 * 16 * 64];
+    const Slice s = sl.s[blockIdx.z];
+    const int M = s.count, tile = blockIdx.x, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int m = tile * 32 + i;
+    const bool ok = m < M;
+    const int k0 = wave * 200 + hl * 100;
+    const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
+    const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
+    f32x16 acc = {0};
+#pragma unroll 1
+    for (int c = 0; c < 5; c++) mma_run_col<20>(arun + 20 * c, ok, bcol + (size_t)20 * c * FC, FC, acc);
+    reduce_waves<8>(acc, red, wave, lane);
+    if (wave == 0) {
+        const float bias = s.params[OFF_WF1 + 1600 * FC + n0 + j];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = tile * 32 + drow(r, lane);
+            if (mr < M) hf[(size_t)(s.s_off + mr) * FC + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+        }
+    }
+}
+
+// fc2 / dueling head (+ epsilon-greedy action for the acting path); one wave per sample
+struct HeadArgs {
+    Slices sl; int nslices; const float *hf; float *q; int FC, A, dueling; NetOff off;
+    uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
+};
+
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int sidx = blockIdx.x * 4 + wave;
+    const float *P = nullptr;
+    int smp = -1;
+    for (int z = 0; z < H.nslices; z++) {
+        if (sidx < H.sl.s[z].count) { P = H.sl.s[z].params; smp = H.sl.s[z].s_off + sidx; break; }
+        sidx -= H.sl.s[z].count;
+    }
+    if (smp < 0) return;
+    const float *h = H.hf + (size_t)smp * H.FC;
+    float acc[MAXA + 1];
+#pragma unroll
+    for (int a = 0; a <= MAXA; a++) acc[a] = 0.f;
+    for (int jj = lane; jj < H.FC; jj += 64) {
+        const float x = h[jj];
+#pragma unroll
+        for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x, P[H.off.wq + jj * H.A + a], acc[a]);
+        if (H.dueling) acc[MAXA] = fmaf(x, P[H.off.wv + jj], acc[MAXA]);
+    }
+#pragma unroll
+    for (int a = 0; a <= MAXA; a++)
+        for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o);
+    float qv[MAXA];
+    float mean = 0.f;
+#pragma unroll
+    for (int a = 0; a < MAXA; a++) { qv[a] = a < H.A ? acc[a] + P[H.off.bq + a] : 0.f; if (a < H.A) mean += qv[a]; }
+    if (H.dueling) {                                             // Q = V + (A - mean_a A)
+        const float V = acc[MAXA] + P[H.off.bv];
+        mean /= (float)H.A;
+#pragma unroll
+        for (int a = 0; a < MAXA; a++) qv[a] = V + (qv[a] - mean);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < MAXA; a++) if (a < H.A) H.q[(size_t)smp * H.A + a] = qv[a];
+        if (H.actions) {                                         // BrainDQN.py:103-108
+            int best = 0;
+#pragma unroll
+            for (int a = 1; a < MAXA; a++) if (a < H.A && qv[a] > qv[best]) best = a;       // np.argmax: first maximum
+            const fb_u4 o = fb_philox(H.seed_lo, H.seed_hi, (uint32_t)smp, H.step_lo, FB_STREAM_EPS, H.step_hi);
+            const float u = (float)(o.x >> 8) * (1.0f / 16777216.0f);                      // random.random()
+            if (u <= H.epsilon) best = (int)(((unsigned long long)o.y * (unsigned)H.A) >> 32);   // randrange(A)
+            H.actions[smp] = (uint8_t)best;
+        }
+    }
+}
+
+// ================================================================== loss + head backward
+struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; };
+
+struct LossArgs {
+    int algo, B, FC, A, dueling;
+    NetOff off;
+    const float *params;            // online
+    const float *q;                 // [3B][A] workspace
+    const float *hf;                // [.][FC], rows 0..B-1 = s through the online net
+    const uint8_t *act; const float *rew; const uint8_t *term; const float *isw;
+    double gamma;
+    float *grad, *dhf, *loss, *abs_err, *y_out;
+    AdamDev *adam; int tick;
+};
+
+__global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
+    __shared__ float dadv[MAXTB][MAXA];
+    __shared__ float dv[MAXTB];
+    __shared__ float lterm[MAXTB];
+    const int tid = threadIdx.x, B = L.B, A = L.A;
+    if (tid < B) {
+        const float *qs = L.q + (size_t)tid * A;
+        const float *qn = L.q + (size_t)(B + tid) * A;          // DQN: online(s'); Nature/PER: target(s'); Double: online(s')
+        float sel;
+        if (L.algo == FB_ALGO_DOUBLE) {                          // BrainDoubleDQN.py:51-54
+            int am = 0;
+            for (int a = 1; a < A; a++) if (qn[a] > qn[am]) am = a;
+            sel = L.q[(size_t)(2 * B + tid) * A + am];
+        } else {
+            sel = qn[0];
+            for (int a = 1; a < A; a++) sel = fmaxf(sel, qn[a]);
+        }
+        // BrainDQN.py:210-215: python float64 arithmetic on the rewards 0.1 / 3 / -3, then fed as float32
+        const float rf = L.rew[tid];
+        const double r = rf == 0.1f ? 0.1 : (double)rf;
+        const double yd = L.term[tid] ? r : r + L.gamma * (double)sel;
+        const float y = (float)yd;
+        const int a_b = L.act[tid];
+        const float d = y - qs[a_b];                             // q_eval = reduce_sum(Q * onehot)
+        const float w = L.algo == FB_ALGO_PER ? L.isw[tid] : 1.f;
+        lterm[tid] = w * d * d;
+        if (L.abs_err) L.abs_err[tid] = fabsf(d);
+        if (L.y_out) L.y_out[tid] = y;
+        const float scale = L.algo == FB_ALGO_DQN ? 2.f : 2.f / (float)B;     // sum vs mean
+        const float g = -scale * w * d;                          // dLoss/dQ[b][a_b]
+        if (L.dueling) {
+            dv[tid] = g;
+            for (int a = 0; a < A; a++) dadv[tid][a] = (a == a_b ? g : 0.f) - g / (float)A;
+        } else {
+            dv[tid] = 0.f;
+            for (int a = 0; a < A; a++) dadv[tid][a] = a == a_b ? g : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; b++) s += lterm[b];
+        *L.loss = L.algo == FB_ALGO_DQN ? s : s / (float)B;
+        if (L.tick) {                                            // Adam step counter for the update that follows
+            AdamDev &ad = *L.adam;
+            ad.alpha = ad.lr * sqrtf(1.f - ad.b2pow) / (1.f - ad.b1pow);
+            ad.b1pow *= ad.b1; ad.b2pow *= ad.b2;
+        }
+    }
+    const float *P = L.params;
+    for (int jj = tid; jj < L.FC; jj += 256) {
+        float gw[MAXA], wrow[MAXA], gv = 0.f, gb = 0.f;
+#pragma unroll
+        for (int a = 0; a < MAXA; a++) { gw[a] = 0.f; wrow[a] = a < A ? P[L.off.wq + jj * A + a] : 0.f; }
+        const float wvj = L.dueling ? P[L.off.wv + jj] : 0.f;
+        for (int b = 0; b < B; b++) {
+            const float h = L.hf[(size_t)b * L.FC + jj];
+            float d = dv[b] * wvj;
+#pragma unroll
+            for (int a = 0; a < MAXA; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
+            gv = fmaf(h, dv[b], gv);
+            const float dh = h > 0.f ? d : 0.f;
+            L.dhf[(size_t)b * L.FC + jj] = dh;
+            gb += dh;
+        }
+#pragma unroll
+        for (int a = 0; a < MAXA; a++) if (a < A) L.grad[L.off.wq + jj * A + a] = gw[a];
+        if (L.dueling) L.grad[L.off.wv + jj] = gv;
+        L.grad[L.off.bf1 + jj] = gb;
+    }
+    if (tid < A) { float s = 0.f; for (int b = 0; b < B; b++) s += dadv[b][tid]; L.grad[L.off.bq + tid] = s; }
+    if (tid == A && L.dueling) { float s = 0.f; for (int b = 0; b < B; b++) s += dv[b]; L.grad[L.off.bv] = s; }
+}
+
+__global__ void adam_tick_kernel(AdamDev *ad) {
+    ad->alpha = ad->lr * sqrtf(1.f - ad->b2pow) / (1.f - ad->b1pow);
+    ad->b1pow *= ad->b1; ad->b2pow *= ad->b2;
+}
+
+// ================================================================== backward
+// dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
+__global__ __launch_bounds__(256) void fc1_dw_kernel(const float *__restrict__ h3, const float *__restrict__ dhf,
+                                                     float *__restrict__ grad, int B, int FC) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int nt_n = FC / 32, tile = blockIdx.x * 4 + wave;
+    if (tile >= 50 * nt_n) return;
+    const int kt = tile / nt_n, nt = tile - kt * nt_n;
+    f32x16 acc = {0};
+#pragma unroll 4
+    for (int t = 0; t < (B + 1) / 2; t++) {
+        const int b = 2 * t + hl;
+        float a = 0.f, bb = 0.f;
+        if (b < B) { a = h3[(size_t)b * 1600 + kt * 32 + i]; bb = dhf[(size_t)b * FC + nt * 32 + j]; }
+        acc = mfma(a, bb, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + j] = acc[r];
+}
+
+// dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 4 waves split n
+__global__ __launch_bounds__(256) void fc1_dx_kernel(const float *__restrict__ params, const float *__restrict__ h3,
+                                                     const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC) {
+    __shared__ float red[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int mt = blockIdx.x, kt = blockIdx.y;
+    const int m = mt * 32 + i;
+    const bool ok = m < B;
+    const int kh = FC / 8, nbeg = wave * (FC / 4) + hl * kh;
+    const float *arun = dhf + (size_t)(ok ? m : 0) * FC + nbeg;
+    const float *brun = params + OFF_WF1 + (size_t)(kt * 32 + j) * FC + nbeg;
+    f32x16 acc = {0};
+    for (int c = 0; c < kh; c += 16) mma_run_run<16>(arun + c, ok, brun + c, acc);
+    reduce_waves<4>(acc, red, wave, lane);
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = mt * 32 + drow(r, lane);
+            if (mr < B) {
+                const size_t o = (size_t)mr * 1600 + kt * 32 + j;
+                dh3[o] = h3[o] > 0.f ? acc[r] : 0.f;
+            }
+        }
+    }
+}
+
+// generic conv weight gradient: dW[(cell, ci)][co] = sum_m X[m @ cell][ci] * dY[m][co].
+// One workgroup = one 32(ci) x 32(co) tile of one kernel cell; its 8 waves (and gridDim.y slabs)
+// split the reduction over output pixels m.
+struct ConvGeom { int OH, OW, IH, IW, CI, CO, K, stride, pad; };
+
+template <bool CONV1>
+__global__ __launch_bounds__(512) void conv_dw_kernel(ConvGeom G, int B, const float *__restrict__ x,
+                                                      const uint8_t *__restrict__ xu8, const float *__restrict__ dy,
+                                                      const uint8_t *__restrict__ amax, float *__restrict__ out,
+                                                      size_t slab_stride, int w_off) {
+    __shared__ float red[7 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int co_tiles = G.CO / 32;
+    int tile = blockIdx.x;
+    const int cot = tile % co_tiles; tile /= co_tiles;
+    // conv1: a "cell" is one kernel row ky with the 32 (kx, f) taps as the tile's 32 ci rows
+    const int ci_tiles = CONV1 ? 1 : G.CI / 32;
+    const int cit = tile % ci_tiles; const int cell = tile / ci_tiles;
+    const int ky = CONV1 ? cell : cell / G.K, kx = CONV1 ? 0 : cell - ky * G.K;
+    const int opix = G.OH * G.OW, M = B * opix;
+    const int parts = gridDim.y * 8;
+    int per = (M + parts - 1) / parts; per += per & 1;
+    const int mbeg = (blockIdx.y * 8 + wave) * per;
+    const int mend = mbeg + per < M ? mbeg + per : M;
+    f32x16 acc = {0};
+#pragma unroll 2
+    for (int mm = mbeg; mm < mend; mm += 2) {
+        const int m = mm + hl;
+        float a = 0.f, bb = 0.f;
+        if (m < mend) {
+            const int b = m / opix, rem = m - b * opix, oy = rem / G.OW, ox = rem - oy * G.OW;
+            const int iy = oy * G.stride + ky - G.pad;
+            if (CONV1) {
+                const int ix = ox * 4 - 2 + (i >> 2);
+                if (iy >= 0 && iy < 80 && ix >= 0 && ix < 80)
+                    a = (float)xu8[(((size_t)b * 80 + iy) * 80 + ix) * 4 + (i & 3)];
+                const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
+                if (amax[po] == ((oy & 1) * 2 + (ox & 1))) bb = dy[po];       // max_pool routes to the arg max
+            } else {
+                const int ix = ox * G.stride + kx - G.pad;
+                if (iy >= 0 && iy < G.IH && ix >= 0 && ix < G.IW)
+                    a = x[(((size_t)b * G.IH + iy) * G.IW + ix) * G.CI + cit * 32 + i];
+                bb = dy[(size_t)m * G.CO + cot * 32 + j];
+            }
+        }
+        acc = mfma(a, bb, acc);
+    }
+    reduce_waves<8>(acc, red, wave, lane);
+    if (wave == 0) {
+        float *o = out + blockIdx.y * slab_stride + w_off;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = CONV1 ? (ky * 32 + drow(r, lane)) : (cell * G.CI + cit * 32 + drow(r, lane));
+            o[(size_t)row * G.CO + cot * 32 + j] = acc[r];
+        }
+    }
+}
+
+// conv3 data gradient -> dh2 (masked by relu2); 9 waves = 9 cells
+__global__ __launch_bounds__(576) void conv3_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh3,
+                                                       const float *__restrict__ h2, float *__restrict__ dh2, int B) {
+    __shared__ float red[8 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int M = B * 25, tile = blockIdx.x, c0 = blockIdx.y * 32;
+    const int ky = wave / 3, kx = wave - ky * 3;
+    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, iy = rem / 5, ix = rem - iy * 5;
+    const int oy = iy + 1 - ky, ox = ix + 1 - kx;
+    const bool ok = m < M && oy >= 0 && oy < 5 && ox >= 0 && ox < 5;
+    const float *arun = dh3 + ((size_t)b * 25 + (ok ? oy * 5 + ox : 0)) * 64 + 32 * hl;
+    const float *brun = params + OFF_W3 + ((size_t)(wave * 64) + c0 + j) * 64 + 32 * hl;
+    f32x16 acc = {0};
+    mma_run_run<32>(arun, ok, brun, acc);
+    reduce_waves<9>(acc, red, wave, lane);
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = tile * 32 + drow(r, lane);
+            if (mr < M) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? acc[r] : 0.f; }
+        }
+    }
+}
+
+// conv2 data gradient -> dp1 (masked by relu1 through the pool: p1 > 0); 8 waves x 2 cells
+__global__ __launch_bounds__(512) void conv2_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh2,
+                                                       const float *__restrict__ p1, float *__restrict__ dp1, int B) {
+    __shared__ float red[7 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int M = B * 100, tile = blockIdx.x;
+    const int m = tile * 32 + i, b = m / 100, rem = m - b * 100, iy = rem / 10, ix = rem - iy * 10;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int cell = wave * 2 + c, ky = cell >> 2, kx = cell & 3;
+        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
+        const bool ok = m < M && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < 5 && (tx >> 1) < 5;
+        const float *arun = dh2 + ((size_t)b * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
+        const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
+        mma_run_run<32>(arun, ok, brun, acc);
+    }
+    reduce_waves<8>(acc, red, wave, lane);
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = tile * 32 + drow(r, lane);
+            if (mr < M) { const size_t o = (size_t)mr * 32 + j; dp1[o] = p1[o] > 0.f ? acc[r] : 0.f; }
+        }
+    }
+}
+
+// conv bias gradients: column sums of dh3 (64), dh2 (64), dp1 (32); one workgroup each
+__global__ __launch_bounds__(256) void conv_bias_kernel(const float *__restrict__ dh3, const float *__restrict__ dh2,
+                                                        const float *__restrict__ dp1, float *__restrict__ grad, int B) {
+    __shared__ float part[256];
+    const int which = blockIdx.x, tid = threadIdx.x;
+    const float *src = which == 0 ? dh3 : (which == 1 ? dh2 : dp1);
+    const int C = which == 2 ? 32 : 64, M = which == 2 ? B * 100 : B * 25, off = which == 0 ? OFF_B3 : (which == 1 ? OFF_B2 : OFF_B1);
+    const int c = tid % C, p = tid / C, np = 256 / C;
+    float s = 0.f;
+    for (int m = p; m < M; m += np) s += src[(size_t)m * C + c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) { float t = 0.f; for (int q = 0; q < np; q++) t += part[q * C + tid]; grad[off + tid] = t; }
+}
+
+// sum the reduction slabs of the conv weight gradients into the flat gradient (fixed order)
+__global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
+                                   float *__restrict__ grad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= CONV_PARAMS) return;
+    int z;
+    if (idx < OFF_B1) z = z1; else if (idx >= OFF_W2 && idx < OFF_B2) z = z2; else if (idx >= OFF_W3 && idx < OFF_B3) z = z3; else return;
+    float s = 0.f;
+    for (int q = 0; q < z; q++) s += slabs[q * slab_stride + idx];
+    grad[idx] = s;
+}
+
+// TF ApplyAdam, fp32, float4 wide
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                   const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad) {
+    const float alpha = ad->alpha, omb1 = 1.f - ad->b1, omb2 = 1.f - ad->b2, eps = ad->eps;
+    const long long n4 = n >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4 *>(p)[q], Mv = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
+        const float4 Gv = reinterpret_cast<const float4 *>(g)[q];
+#define FB_ADAM1(c)                                  \
+        Mv.c += (Gv.c - Mv.c) * omb1;                \
+        V.c += (Gv.c * Gv.c - V.c) * omb2;           \
+        P.c -= (Mv.c * alpha) / (sqrtf(V.c) + eps);
+        FB_ADAM1(x) FB_ADAM1(y) FB_ADAM1(z) FB_ADAM1(w)
+#undef FB_ADAM1
+        reinterpret_cast<float4 *>(p)[q] = P; reinterpret_cast<float4 *>(m)[q] = Mv; reinterpret_cast<float4 *>(v)[q] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long q = (n4 << 2) + threadIdx.x;
+        float mm = m[q], vv = v[q];
+        mm += (g[q] - mm) * omb1; vv += (g[q] * g[q] - vv) * omb2;
+        p[q] -= (mm * alpha) / (sqrtf(vv) + eps);
+        m[q] = mm; v[q] = vv;
+    }
+}
+
+// tf.truncated_normal(stddev=0.01) weights, 0.01 biases (BrainDQN.py:123-152)
+__global__ void init_params_kernel(float *__restrict__ p, long long n, NetOff off, int FC, int A, int dueling,
+                                   uint32_t seed_lo, uint32_t seed_hi) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool bias = (i >= OFF_B1 && i < OFF_W2) || (i >= OFF_B2 && i < OFF_W3) || (i >= OFF_B3 && i < OFF_WF1) ||
+                (i >= off.bf1 && i < off.bf1 + FC) || (i >= off.bq && i < off.bq + A) || (dueling && i == off.bv);
+    if (bias) { p[i] = 0.01f; return; }
+    for (uint32_t ctr = 0;; ctr++) {
+        const fb_u4 r = fb_philox(seed_lo, seed_hi, (uint32_t)i, ctr, FB_STREAM_INIT, 0u);
+        const float u1 = ((r.x >> 8) + 1) * (1.0f / 16777216.0f), u2 = (r.y >> 8) * (1.0f / 16777216.0f);
+        const float z = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+        if (fabsf(z) <= 2.f) { p[i] = 0.01f * z; return; }
+    }
+}
+
+}  // namespace
+
+// ================================================================== host side
+struct fb_qnet {
+    int arch, FC, A, max_batch;
+    long long n;
+    NetOff off;
+    float *params[2], *adam_m, *adam_v, *grad, *slabs;
+    AdamDev *adam;
+    // workspace for 3 * max_batch samples
+    float *p1, *h2, *h3, *hf, *q;
+    uint8_t *amax;
+    float *dhf, *dh3, *dh2, *dp1;
+    int zmax;
+};
+
+static NetOff make_off(int FC, int A, int dueling) {
+    NetOff o;
+    o.bf1 = OFF_WF1 + 1600 * FC;
+    int p = o.bf1 + FC;
+    if (dueling) { o.wv = p; o.bv = p + FC; p = o.bv + 1; } else { o.wv = 0; o.bv = 0; }
+    o.wq = p; o.bq = p + FC * A; o.n = o.bq + A;
+    return o;
+}
+
+extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_batch, fb_qnet_t *out) {
+    FB_REQUIRE(out, "fb_qnet_create: out is NULL");
+    FB_REQUIRE(arch == FB_ARCH_PLAIN || arch == FB_ARCH_DUELING, "fb_qnet_create: arch must be 0 or 1");
+    FB_REQUIRE(fc_width >= 128 && fc_width <= 4096 && fc_width % 128 == 0, "fb_qnet_create: fc_width must be a multiple of 128");
+    FB_REQUIRE(n_actions >= 1 && n_actions <= MAXA, "fb_qnet_create: n_actions must be in 1..%d", MAXA);
+    FB_REQUIRE(max_batch >= 1 && max_batch <= (1 << 20), "fb_qnet_create: max_batch out of range");
+    fb_qnet *h = new fb_qnet();
+    memset(h, 0, sizeof(*h));
+    h->arch = arch; h->FC = fc_width; h->A = n_actions; h->max_batch = max_batch;
+    h->off = make_off(fc_width, n_actions, arch == FB_ARCH_DUELING);
+    h->n = h->off.n;
+    h->zmax = 32;
+    const size_t S = (size_t)3 * max_batch, nb = sizeof(float) * (size_t)h->n;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); };
+    alloc((void **)&h->params[0], nb); alloc((void **)&h->params[1], nb);
+    alloc((void **)&h->adam_m, nb); alloc((void **)&h->adam_v, nb); alloc((void **)&h->grad, nb);
+    alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
+    alloc((void **)&h->adam, sizeof(AdamDev));
+    alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
+    alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
+    alloc((void **)&h->hf, S * fc_width * 4); alloc((void **)&h->q, S * MAXA * 4);
+    const size_t Bm = max_batch;
+    alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
+    alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
+    if (e != hipSuccess) {
+        fb_set_error(e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP, "fb_qnet_create: %s", hipGetErrorString(e));
+        fb_qnet_destroy(h);
+        return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
+    }
+    *out = h;
+    return fb_qnet_set_hparams(h, 1e-6f, 0.9f, 0.999f, 1e-8f);
+}
+
+extern "C" int fb_qnet_destroy(fb_qnet_t h) {
+    if (!h) return FB_OK;
+    void *ptrs[] = {h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+                    h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_num_params(fb_qnet_t h, int64_t *n_host) {
+    FB_REQUIRE(h && n_host, "fb_qnet_num_params: NULL argument");
+    *n_host = h->n;
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float eps) {
+    FB_REQUIRE(h, "fb_qnet_set_hparams: NULL handle");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    AdamDev a;
+    FB_CHECK_HIP(hipMemcpy(&a, h->adam, sizeof(a), hipMemcpyDeviceToHost));
+    const bool fresh = a.b1 == 0.f && a.b2 == 0.f;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    if (fresh) { a.b1pow = beta1; a.b2pow = beta2; a.alpha = 0.f; }      // beta1_power / beta2_power initial values
+    FB_CHECK_HIP(hipMemcpy(h->adam, &a, sizeof(a), hipMemcpyHostToDevice));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *stream) {
+    FB_REQUIRE(h && (which == 0 || which == 1), "fb_qnet_init_params: bad argument");
+    hipLaunchKernelGGL(init_params_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, fb_stream(stream),
+                       h->params[which], h->n, h->off, h->FC, h->A, h->arch == FB_ARCH_DUELING, (uint32_t)seed,
+                       (uint32_t)(seed >> 32));
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat, void *stream) {
+    FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_load_params: bad argument");
+    FB_CHECK_HIP(hipMemcpyAsync(h->params[which], flat, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_store_params(fb_qnet_t h, int which, float *flat, void *stream) {
+    FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_store_params: bad argument");
+    FB_CHECK_HIP(hipMemcpyAsync(flat, h->params[which], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_get_adam_state(fb_qnet_t h, float *m, float *v, float *beta_pows_host) {
+    FB_REQUIRE(h, "fb_qnet_get_adam_state: NULL handle");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    const size_t nb = sizeof(float) * (size_t)h->n;
+    if (m) FB_CHECK_HIP(hipMemcpy(m, h->adam_m, nb, hipMemcpyDeviceToDevice));
+    if (v) FB_CHECK_HIP(hipMemcpy(v, h->adam_v, nb, hipMemcpyDeviceToDevice));
+    if (beta_pows_host) {
+        AdamDev a;
+        FB_CHECK_HIP(hipMemcpy(&a, h->adam, sizeof(a), hipMemcpyDeviceToHost));
+        beta_pows_host[0] = a.b1pow; beta_pows_host[1] = a.b2pow;
+    }
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *v, const float *beta_pows_host) {
+    FB_REQUIRE(h, "fb_qnet_set_adam_state: NULL handle");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    const size_t nb = sizeof(float) * (size_t)h->n;
+    if (m) FB_CHECK_HIP(hipMemcpy(h->adam_m, m, nb, hipMemcpyDeviceToDevice));
+    if (v) FB_CHECK_HIP(hipMemcpy(h->adam_v, v, nb, hipMemcpyDeviceToDevice));
+    if (beta_pows_host) {
+        AdamDev a;
+        FB_CHECK_HIP(hipMemcpy(&a, h->adam, sizeof(a), hipMemcpyDeviceToHost));
+        a.b1pow = beta_pows_host[0]; a.b2pow = beta_pows_host[1];
+        FB_CHECK_HIP(hipMemcpy(h->adam, &a, sizeof(a), hipMemcpyHostToDevice));
+    }
+    return FB_OK;
+}
+
+// conv1 .. fc1 .. head for up to three (params, states) slices in one launch per layer
+static int run_forward(fb_qnet *h, const Slices &sl, int nslices, hipStream_t st, uint8_t *actions, float epsilon,
+                       uint64_t seed, uint64_t step) {
+    int maxc = 0, total = 0;
+    for (int z = 0; z < nslices; z++) { if (sl.s[z].count > maxc) maxc = sl.s[z].count; total += sl.s[z].count; }
+    hipLaunchKernelGGL(conv1_pool_kernel, dim3((maxc * 100 + 7) / 8, 1, nslices), dim3(256), 0, st, sl, h->p1, h->amax);
+    hipLaunchKernelGGL(conv2_kernel, dim3((maxc * 25 + 31) / 32, 2, nslices), dim3(512), 0, st, sl, h->p1, h->h2);
+    hipLaunchKernelGGL(conv3_kernel, dim3((maxc * 25 + 31) / 32, 2, nslices), dim3(576), 0, st, sl, h->h2, h->h3);
+    hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, nslices), dim3(512), 0, st, sl, h->h3, h->hf, h->FC);
+    HeadArgs H;
+    H.sl = sl; H.nslices = nslices; H.hf = h->hf; H.q = h->q; H.FC = h->FC; H.A = h->A;
+    H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = actions; H.epsilon = epsilon;
+    H.seed_lo = (uint32_t)seed; H.seed_hi = (uint32_t)(seed >> 32); H.step_lo = (uint32_t)step; H.step_hi = (uint32_t)(step >> 32);
+    hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream) {
+    FB_REQUIRE(h && states && q && (which == 0 || which == 1), "fb_qnet_forward: bad argument");
+    FB_REQUIRE(batch >= 1 && batch <= 3 * h->max_batch, "fb_qnet_forward: batch %d exceeds 3*max_batch", batch);
+    Slices sl; memset(&sl, 0, sizeof(sl));
+    sl.s[0] = Slice{h->params[which], states, 0, batch};
+    int rc = run_forward(h, sl, 1, fb_stream(stream), nullptr, 0.f, 0, 0);
+    if (rc != FB_OK) return rc;
+    FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)batch * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsilon, uint64_t seed, uint64_t step,
+                           uint8_t *actions, float *q, void *stream) {
+    FB_REQUIRE(h && states && actions, "fb_qnet_act: NULL argument");
+    FB_REQUIRE(n >= 1 && n <= 3 * h->max_batch, "fb_qnet_act: n %d exceeds 3*max_batch", n);
+    Slices sl; memset(&sl, 0, sizeof(sl));
+    sl.s[0] = Slice{h->params[0], states, 0, n};
+    int rc = run_forward(h, sl, 1, fb_stream(stream), actions, epsilon, seed, step);
+    if (rc != FB_OK) return rc;
+    if (q) FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)n * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream) {
+    FB_REQUIRE(h && flat_grad, "fb_qnet_apply_adam: NULL argument");
+    hipStream_t st = fb_stream(stream);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
+    hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
+    FB_REQUIRE(h, "fb_qnet_sync_target: NULL handle");
+    FB_CHECK_HIP(hipMemcpyAsync(h->params[1], h->params[0], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_train_step(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r,
+                                  const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
+                                  float *abs_err, float *q_target, float *flat_grad, void *stream) {
+    FB_REQUIRE(h && s && a && r && s2 && t && loss, "fb_qnet_train_step: NULL argument");
+    FB_REQUIRE(algo >= 0 && algo <= 3, "fb_qnet_train_step: unknown algo %d", algo);
+    FB_REQUIRE(B >= 1 && B <= h->max_batch && B <= MAXTB, "fb_qnet_train_step: batch %d exceeds min(max_batch, %d)", B, MAXTB);
+    FB_REQUIRE(algo != FB_ALGO_PER || isw, "fb_qnet_train_step: PER needs isw");
+    hipStream_t st = fb_stream(stream);
+    float *G = flat_grad ? flat_grad : h->grad;
+    // ---- forward: s through the online net, s' through the net(s) the algorithm asks for
+    Slices sl; memset(&sl, 0, sizeof(sl));
+    int ns = 2;
+    sl.s[0] = Slice{h->params[0], s, 0, B};
+    if (algo == FB_ALGO_DQN) sl.s[1] = Slice{h->params[0], s2, B, B};                 // BrainDQN.py:205 (same net)
+    else if (algo == FB_ALGO_DOUBLE) { sl.s[1] = Slice{h->params[0], s2, B, B}; sl.s[2] = Slice{h->params[1], s2, 2 * B, B}; ns = 3; }
+    else sl.s[1] = Slice{h->params[1], s2, B, B};                                     // target net
+    int rc = run_forward(h, sl, ns, st, nullptr, 0.f, 0, 0);
+    if (rc != FB_OK) return rc;
+    // ---- targets, loss, head backward
+    LossArgs L;
+    L.algo = algo; L.B = B; L.FC = h->FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
+    L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.act = a; L.rew = r; L.term = t; L.isw = isw; L.gamma = gamma;
+    L.grad = G; L.dhf = h->dhf; L.loss = loss; L.abs_err = abs_err; L.y_out = q_target; L.adam = h->adam;
+    L.tick = flat_grad == nullptr;
+    hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, st, L);
+    // ---- backward
+    const int FC = h->FC;
+    hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, st, h->h3, h->dhf, G, B, FC);
+    hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(256), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
+    int z3 = (B * 25 + 1023) / 1024, z2 = z3, z1 = (B * 400 + 1023) / 1024;           // >= 64 pixel pairs per wave
+    if (z3 > h->zmax) z3 = z2 = h->zmax;
+    if (z1 > h->zmax) z1 = h->zmax;
+    const size_t ss = CONV_PARAMS;
+    const ConvGeom g3{5, 5, 5, 5, 64, 64, 3, 1, 1}, g2{5, 5, 10, 10, 32, 64, 4, 2, 1}, g1{20, 20, 80, 80, 4, 32, 8, 4, 2};
+    hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(36, z3), dim3(512), 0, st, g3, B, h->h2, (const uint8_t *)nullptr, h->dh3,
+                       (const uint8_t *)nullptr, h->slabs, ss, OFF_W3);
+    hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
+    hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(32, z2), dim3(512), 0, st, g2, B, h->p1, (const uint8_t *)nullptr, h->dh2,
+                       (const uint8_t *)nullptr, h->slabs, ss, OFF_W2);
+    hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 100 + 31) / 32), dim3(512), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
+    hipLaunchKernelGGL(conv_dw_kernel<true>, dim3(8, z1), dim3(512), 0, st, g1, B, (const float *)nullptr, s, h->dp1, h->amax,
+                       h->slabs, ss, OFF_W1);
+    hipLaunchKernelGGL(conv_bias_kernel, dim3(3), dim3(256), 0, st, h->dh3, h->dh2, h->dp1, G, B);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
+    if (!flat_grad)
+        hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}

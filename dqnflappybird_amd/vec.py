@@ -185,3 +185,110 @@ class VecReplay:
         L.check(L.lib().fb_replay_per_tree(self.h, L.ptr(tree), C.byref(ptr_), C.byref(size), C.byref(beta)),
                 "fb_replay_per_tree")
         return tree, ptr_.value, size.value, beta.value
+
+
+ALGOS = {"dqn": L.ALGO_DQN, "nature": L.ALGO_NATURE, "double": L.ALGO_DOUBLE, "per": L.ALGO_PER}
+
+
+class QNet:
+    """The reference Q-network (BrainDQN.py:119-163) with forward, backward and TF-Adam as HIP
+    kernels.  `arch='dueling'` builds the head of BrainDuelingDQN.py:78-86."""
+
+    def __init__(self, actions=2, fc_width=512, arch="plain", max_batch=32, device="cuda"):
+        L.require_gpu()
+        self.A, self.FC, self.max_batch = int(actions), int(fc_width), int(max_batch)
+        self.dueling = arch == "dueling"
+        self.device = torch.device(device)
+        self.h = C.c_void_p()
+        L.check(L.lib().fb_qnet_create(L.ARCH_DUELING if self.dueling else L.ARCH_PLAIN, self.FC, self.A, self.max_batch,
+                                       C.byref(self.h)), "fb_qnet_create")
+        n = C.c_int64()
+        L.check(L.lib().fb_qnet_num_params(self.h, C.byref(n)), "fb_qnet_num_params")
+        self.n_params = n.value
+        self._buf = {}
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            L.lib().fb_qnet_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _get(self, name, shape, dtype):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    # -- parameters -----------------------------------------------------------------
+    def init_params(self, seed=0, which=L.NET_ONLINE):
+        L.check(L.lib().fb_qnet_init_params(self.h, which, seed, L.current_stream()), "fb_qnet_init_params")
+
+    def load_params(self, flat, which=L.NET_ONLINE):
+        if not torch.is_tensor(flat):
+            flat = torch.from_numpy(np.ascontiguousarray(flat, np.float32)).to(self.device)
+        _dev_check(flat)
+        if flat.dtype != torch.float32 or flat.numel() != self.n_params:
+            raise ValueError(f"expected float32[{self.n_params}]")
+        L.check(L.lib().fb_qnet_load_params(self.h, which, L.ptr(flat), L.current_stream()), "fb_qnet_load_params")
+        torch.cuda.current_stream().synchronize()     # `flat` may be a temporary
+
+    def store_params(self, which=L.NET_ONLINE):
+        out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        L.check(L.lib().fb_qnet_store_params(self.h, which, L.ptr(out), L.current_stream()), "fb_qnet_store_params")
+        return out
+
+    def set_hparams(self, lr=1e-6, beta1=0.9, beta2=0.999, eps=1e-8):
+        L.check(L.lib().fb_qnet_set_hparams(self.h, lr, beta1, beta2, eps), "fb_qnet_set_hparams")
+
+    def adam_state(self):
+        m = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        v = torch.empty_like(m)
+        pows = np.empty(2, np.float32)
+        L.check(L.lib().fb_qnet_get_adam_state(self.h, L.ptr(m), L.ptr(v), L.ptr(pows)), "fb_qnet_get_adam_state")
+        return m, v, pows
+
+    def set_adam_state(self, m, v, pows):
+        pows = np.ascontiguousarray(pows, np.float32)
+        _dev_check(m, v)
+        L.check(L.lib().fb_qnet_set_adam_state(self.h, L.ptr(m), L.ptr(v), L.ptr(pows)), "fb_qnet_set_adam_state")
+
+    def sync_target(self):
+        L.check(L.lib().fb_qnet_sync_target(self.h, L.current_stream()), "fb_qnet_sync_target")
+
+    # -- compute --------------------------------------------------------------------
+    def forward(self, states, which=L.NET_ONLINE):
+        _dev_check(states)
+        B = states.shape[0]
+        if states.dtype != torch.uint8 or tuple(states.shape[1:]) != (80, 80, 4):
+            raise ValueError("states must be uint8[B,80,80,4]")
+        q = self._get(f"q{B}", (B, self.A), torch.float32)
+        L.check(L.lib().fb_qnet_forward(self.h, which, L.ptr(states), B, L.ptr(q), L.current_stream()), "fb_qnet_forward")
+        return q
+
+    def act(self, states, epsilon, seed=0, step=0, want_q=False):
+        _dev_check(states)
+        n = states.shape[0]
+        actions = self._get(f"act{n}", (n,), torch.uint8)
+        q = self._get(f"qa{n}", (n, self.A), torch.float32) if want_q else None
+        L.check(L.lib().fb_qnet_act(self.h, L.ptr(states), n, float(epsilon), seed, step, L.ptr(actions), L.ptr(q),
+                                    L.current_stream()), "fb_qnet_act")
+        return (actions, q) if want_q else actions
+
+    def train_step(self, algo, s, a, r, s2, t, isw=None, gamma=0.99, flat_grad=None, want_aux=True):
+        """One _trainQNetwork step.  Returns (loss f32[1], abs_err f32[B], q_target f32[B]) device tensors.
+        flat_grad=None applies Adam; a float32[n_params] tensor receives the gradients instead."""
+        _dev_check(s, a, r, s2, t, isw, flat_grad)
+        B = s.shape[0]
+        loss = self._get("loss", (1,), torch.float32)
+        ae = self._get(f"ae{B}", (B,), torch.float32) if want_aux else None
+        y = self._get(f"y{B}", (B,), torch.float32) if want_aux else None
+        if isw is not None and isw.dtype != torch.float32:
+            isw = isw.to(torch.float32)          # ISWeights is fed to a float32 placeholder
+        L.check(L.lib().fb_qnet_train_step(self.h, ALGOS[algo] if isinstance(algo, str) else algo, B, L.ptr(s), L.ptr(a),
+                                           L.ptr(r), L.ptr(s2), L.ptr(t), L.ptr(isw), float(gamma), L.ptr(loss), L.ptr(ae),
+                                           L.ptr(y), L.ptr(flat_grad), L.current_stream()), "fb_qnet_train_step")
+        return loss, ae, y
+
+    def apply_adam(self, flat_grad):
+        _dev_check(flat_grad)
+        L.check(L.lib().fb_qnet_apply_adam(self.h, L.ptr(flat_grad), L.current_stream()), "fb_qnet_apply_adam")
