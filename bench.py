@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- the contract benchmark of the MI355X Flappy-Bird DQN hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): per GPU 1024 vectorised envs + BrainDQN (uniform replay,
+1 M-slot ring, batch 32, fp32).  One *step* = one pass of the whole hot path over one batch of
+envs: currentState -> getAction for 1024 envs (forward + epsilon-greedy) -> frame_step (render +
+preprocess fused) -> store -> random.sample(32) -> minibatch gather -> _trainQNetwork (target
+forward, forward, backward, Adam; with N > 1 one RCCL all-reduce of the flat gradient).
+`value` = env-steps/s over all ranks in that loop.  The train-only leg (sample -> gather -> train)
+gives `grad_steps_per_sec`, the env-only leg `env_only_steps_per_sec`.  Everything is device
+resident when the timed region starts; nothing crosses PCIe inside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ENVS, BATCH, CAPACITY = 1024, 32, 1_000_000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+
+# algorithmic flops / bytes per launch (n = samples in the launch)
+FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64 * 512,
+            "conv3_kernel": 2 * 25 * 64 * 576, "fc1_kernel": 2 * 1600 * 512, "head_kernel": 2 * 512 * 2}
+BWD_FLOP = {"fc1_dw_kernel": 2 * 1600 * 512, "fc1_dx_kernel": 2 * 1600 * 512, "conv_dw_kernel<conv3>": 2 * 25 * 576 * 64,
+            "conv3_dx_kernel": 2 * 25 * 576 * 64, "conv_dw_kernel<conv2>": 2 * 25 * 512 * 64,
+            "conv2_dx_kernel": 2 * 25 * 512 * 64, "conv_dw_kernel<conv1>": 2 * 400 * 256 * 32}
+GATHER_BYTES = 102_417          # per sampled transition
+ADAM_BYTES = 28                 # per parameter
+ENV_BYTES = 6_400 + 64          # per env-step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-legs", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dqnflappybird_amd import _lib as L
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    L.require_gpu()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- build the pipeline
+    seed = 0
+    env = VecGameState(N_ENVS, seed=seed + rank)            # envs shard by rank, own Philox streams
+    replay = VecReplay(CAPACITY, N_ENVS)
+    replay.seed(seed + rank, "cpython")                     # bit-exact random.sample stream
+    net = QNet(2, 512, "plain", max_batch=N_ENVS)
+    net.init_params(seed=seed)                              # identical replicas on every rank
+    grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda") if world > 1 else None
+    env.observe()
+    replay.reset(env.frame_bits)
+    eps = 0.03                                              # INITIAL_EPSILON (BrainDQN.py:25)
+
+    def train(step):
+        idx, _ = replay.sample(BATCH)
+        s, a, r, s2, t = replay.gather(idx)
+        if world > 1:
+            net.train_step("dqn", s, a, r, s2, t, flat_grad=grad, want_aux=False)
+            dist.all_reduce(grad)                           # sum loss (BrainDQN.py:162) -> plain sum
+            net.apply_adam(grad)
+        else:
+            net.train_step("dqn", s, a, r, s2, t, want_aux=False)
+
+    def full_step(step):
+        states = replay.current_state()
+        actions = net.act(states, eps, seed=seed + rank, step=step)
+        env.frame_step(actions, want_u8=False)
+        replay.push(env.frame_bits, actions, env.reward, env.terminal)
+        train(step)
+
+    def timed(fn, k, first=0):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            fn(first + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt
+
+    # ---------------------------------------------------------------- leg A: the full loop (value)
+    for i in range(args.warmup):
+        full_step(i)
+    dt = timed(full_step, args.steps, first=args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    env_steps_per_s = world * N_ENVS * args.steps / dt
+
+    # ---------------------------------------------------------------- leg B: env only
+    acts = (torch.rand(N_ENVS, device="cuda") < 0.1).to(torch.uint8)
+    dt_env = timed(lambda i: env.frame_step(acts, want_u8=False), args.steps)
+    env_only = world * N_ENVS * args.steps / dt_env
+
+    # ---------------------------------------------------------------- leg C: train only (sample -> gather -> train)
+    graph_used = False
+    if world == 1:
+        try:                                                # one hipGraph = 10 train steps, no host work inside
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                train(0)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                for _ in range(10):
+                    train(0)
+            g.replay()
+            torch.cuda.synchronize()
+            graph_used = True
+        except Exception as e:                              # pragma: no cover
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); eager train leg", file=sys.stderr)
+    if graph_used:
+        reps = max(1, args.steps // 10)
+        dt_tr = timed(lambda i: g.replay(), reps)
+        grad_steps = 10 * reps
+    else:
+        dt_tr = timed(train, args.steps)
+        grad_steps = args.steps
+    grad_steps_per_s = world * grad_steps / dt_tr
+    dt_tr_eager = timed(train, args.steps)
+    grad_steps_eager = world * args.steps / dt_tr_eager
+
+    # ---------------------------------------------------------------- leg D: per-kernel HIP-event timing
+    kernels = []
+    roofline = None
+    if rank == 0 and not args.no_kernel_legs:
+        def ev_time(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                     # torch's current stream == the stream we launch on
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps         # us per launch
+
+        def add(name, us, per_step, bound, work):
+            peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF
+            ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
+            kernels.append({"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
+                            "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                            "frac": round(ach / peak, 5)})
+
+        scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
+        scratch.init_params(seed=1)
+        idx, _ = replay.sample(BATCH)
+        s, a, r, s2, t = replay.gather(idx)
+        states = replay.current_state()
+        loss = torch.zeros(1, device="cuda")
+        scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
+        R = 50
+        lib = L.lib()
+        st = L.current_stream
+        # acting forward, n = 1024
+        scratch.act(states, 0.0)
+        for k in range(5):
+            name = lib.fb_qnet_kernel_name(k).decode()
+            us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -1, N_ENVS, L.ptr(states), None, None, None,
+                                                                  None, None, st()), "profile"), R)
+            add(name + "[act n=1024]", us, 1, "mfma", FWD_FLOP[name] * N_ENVS)
+        # train step, B = 32 (forward kernels see 2B samples: s and s')
+        scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
+        for k in range(16):
+            name = lib.fb_qnet_kernel_name(k).decode()
+            us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, 0, BATCH, L.ptr(s), L.ptr(a), L.ptr(r),
+                                                                  L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
+            if name in FWD_FLOP:
+                add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
+            elif name in BWD_FLOP:
+                add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
+            elif name == "adam_kernel":
+                add(name, us, 1, "hbm", ADAM_BYTES * net.n_params)
+            else:
+                add(name, us, 1, "hbm", 0)
+        us = ev_time(lambda: [replay.gather(idx) for _ in range(R)], R)
+        add("gather_kernel<false>[B=32]", us, 1, "hbm", GATHER_BYTES * BATCH)
+        big = torch.randint(0, 100000, (4096,), dtype=torch.int64, device="cuda")
+        bigrep = [torch.empty((4096, 80, 80, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        bm = [torch.empty(4096, dtype=dt_, device="cuda") for dt_ in (torch.uint8, torch.float32, torch.uint8)]
+
+        def big_gather():
+            for _ in range(10):
+                L.check(lib.fb_replay_gather(replay.h, 4096, L.ptr(big), L.ptr(bigrep[0]), L.ptr(bigrep[1]), L.ptr(bm[0]),
+                                             L.ptr(bm[1]), L.ptr(bm[2]), st()), "gather")
+        us = ev_time(big_gather, 10)
+        add("gather_kernel<false>[B=4096]", us, 0, "hbm", GATHER_BYTES * 4096)
+        us = ev_time(lambda: [replay.current_state() for _ in range(R)], R)
+        add("gather_kernel<true>[currentState n=1024]", us, 1, "hbm", 2 * 25_600 * N_ENVS)
+        us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
+        add("env_kernel<true>[n=1024]", us, 1, "hbm", ENV_BYTES * N_ENVS)
+        dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC bytes per launch from the rocprofv3 --pmc pass
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom["kernel"].split("[")[0])
+        roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc                    # the checker, timed as the reported baseline
+        res = orc.reference_loop(observe_steps=150, train_steps=25, replay_cap=50000, seed=0)
+        cpu = {"value": round(res["env_steps_per_s"], 2), "unit": "env-steps/s", "cores": 1, "kind": "port",
+               "grad_steps_per_sec": round(res["grad_steps_per_s"], 3),
+               "sample": f"oracle single-env loop of FlappyBirdDQN.py:72-76 (batch-1 act, full render + preprocess, "
+                         f"store, random.sample(32), train): {res['env_steps']} env steps incl. {res['grad_steps']} "
+                         f"train steps in {res['seconds']:.1f} s, fp64-accumulating scalar C, 1 thread, no 30 FPS cap"}
+
+    if rank == 0:
+        out = {
+            "metric": "env steps/sec (whole node) + DQN grad-steps/sec, 80x80x4 batch=32",
+            "value": round(env_steps_per_s, 1), "unit": "env-steps/s",
+            "grad_steps_per_sec": round(grad_steps_per_s, 1),
+            "grad_steps_per_sec_eager": round(grad_steps_eager, 1),
+            "env_only_steps_per_sec": round(env_only, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",
+                       "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
+                       "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
+                       "train_leg": "hipGraph x10" if graph_used else "eager",
+                       "parallelism": f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat "
+                                      f"gradient per step" if world > 1 else "single GPU"},
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

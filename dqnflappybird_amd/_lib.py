@@ -60,6 +60,8 @@ SIGNATURES = {
     "fb_qnet_train_step": [_vp, _i, _i] + [_vp] * 6 + [_d] + [_vp] * 5,
     "fb_qnet_apply_adam": [_vp, _vp, _vp],
     "fb_qnet_sync_target": [_vp, _vp],
+    "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
+    "fb_qnet_kernel_name": [_i],
 }
 
 _lib = None
@@ -80,7 +82,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError = stale library: rebuild it
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "fb_last_error" else C.c_int
+            fn.restype = C.c_char_p if name in ("fb_last_error", "fb_qnet_kernel_name") else C.c_int
         _lib = L
     return _lib
 

@@ -722,30 +722,86 @@ extern "C" int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *
     return FB_OK;
 }
 
-// conv1 .. fc1 .. head for up to three (params, states) slices in one launch per layer
-static int run_forward(fb_qnet *h, const Slices &sl, int nslices, hipStream_t st, uint8_t *actions, float epsilon,
-                       uint64_t seed, uint64_t step) {
+// ------------------------------------------------------------------ launch plan
+// Every kernel of a forward / train step, individually addressable so that bench.py can time one
+// kernel on the caller's stream (fb_qnet_profile_kernel) with exactly the launch geometry the real
+// step uses.  `only` < 0 launches the whole plan.
+enum KernelId {
+    K_CONV1 = 0, K_CONV2, K_CONV3, K_FC1, K_HEAD, K_LOSS, K_FC1_DW, K_FC1_DX, K_CONV3_DW, K_CONV3_DX, K_CONV2_DW,
+    K_CONV2_DX, K_CONV1_DW, K_BIAS, K_SLAB, K_ADAM, K_COUNT
+};
+
+struct Plan {
+    Slices sl; int ns;                       // forward slices
+    uint8_t *actions; float epsilon; uint64_t seed, step;
+    bool train;                              // forward only when false
+    int algo, B; const uint8_t *s, *a, *t; const float *r, *isw; double gamma;
+    float *loss, *abs_err, *y, *G; bool apply_adam, tick;
+};
+
+static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
+#define FB_K(id) if (only < 0 || only == (id))
     int maxc = 0, total = 0;
-    for (int z = 0; z < nslices; z++) { if (sl.s[z].count > maxc) maxc = sl.s[z].count; total += sl.s[z].count; }
-    hipLaunchKernelGGL(conv1_pool_kernel, dim3((maxc * 100 + 7) / 8, 1, nslices), dim3(256), 0, st, sl, h->p1, h->amax);
-    hipLaunchKernelGGL(conv2_kernel, dim3((maxc * 25 + 31) / 32, 2, nslices), dim3(512), 0, st, sl, h->p1, h->h2);
-    hipLaunchKernelGGL(conv3_kernel, dim3((maxc * 25 + 31) / 32, 2, nslices), dim3(576), 0, st, sl, h->h2, h->h3);
-    hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, nslices), dim3(512), 0, st, sl, h->h3, h->hf, h->FC);
-    HeadArgs H;
-    H.sl = sl; H.nslices = nslices; H.hf = h->hf; H.q = h->q; H.FC = h->FC; H.A = h->A;
-    H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = actions; H.epsilon = epsilon;
-    H.seed_lo = (uint32_t)seed; H.seed_hi = (uint32_t)(seed >> 32); H.step_lo = (uint32_t)step; H.step_hi = (uint32_t)(step >> 32);
-    hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
+    for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
+    FB_K(K_CONV1) hipLaunchKernelGGL(conv1_pool_kernel, dim3((maxc * 100 + 7) / 8, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+    FB_K(K_CONV2) hipLaunchKernelGGL(conv2_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
+    FB_K(K_CONV3) hipLaunchKernelGGL(conv3_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
+    FB_K(K_FC1) hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC);
+    FB_K(K_HEAD) {
+        HeadArgs H;
+        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.q = h->q; H.FC = h->FC; H.A = h->A;
+        H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
+        H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
+        H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
+        hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
+    }
+    if (p.train) {
+        const int B = p.B, FC = h->FC;
+        float *G = p.G;
+        FB_K(K_LOSS) {
+            LossArgs L;
+            L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
+            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
+            L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
+            L.adam = h->adam; L.tick = p.tick;
+            hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, st, L);
+        }
+        FB_K(K_FC1_DW) hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, st, h->h3, h->dhf, G, B, FC);
+        FB_K(K_FC1_DX) hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(256), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
+        int z3 = (B * 25 + 1023) / 1024, z2 = z3, z1 = (B * 400 + 1023) / 1024;       // >= 64 pixel pairs per wave
+        if (z3 > h->zmax) z3 = z2 = h->zmax;
+        if (z1 > h->zmax) z1 = h->zmax;
+        const size_t ss = CONV_PARAMS;
+        const ConvGeom g3{5, 5, 5, 5, 64, 64, 3, 1, 1}, g2{5, 5, 10, 10, 32, 64, 4, 2, 1}, g1{20, 20, 80, 80, 4, 32, 8, 4, 2};
+        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(36, z3), dim3(512), 0, st, g3, B, h->h2, (const uint8_t *)nullptr,
+                                            h->dh3, (const uint8_t *)nullptr, h->slabs, ss, OFF_W3);
+        FB_K(K_CONV3_DX) hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
+        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(32, z2), dim3(512), 0, st, g2, B, h->p1, (const uint8_t *)nullptr,
+                                            h->dh2, (const uint8_t *)nullptr, h->slabs, ss, OFF_W2);
+        FB_K(K_CONV2_DX) hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 100 + 31) / 32), dim3(512), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
+        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv_dw_kernel<true>, dim3(8, z1), dim3(512), 0, st, g1, B, (const float *)nullptr, p.s, h->dp1,
+                                            h->amax, h->slabs, ss, OFF_W1);
+        FB_K(K_BIAS) hipLaunchKernelGGL(conv_bias_kernel, dim3(3), dim3(256), 0, st, h->dh3, h->dh2, h->dp1, G, B);
+        FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
+        if (p.apply_adam) FB_K(K_ADAM)
+            hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam);
+    }
+#undef FB_K
     FB_LAUNCH_CHECK();
     return FB_OK;
+}
+
+static Plan forward_plan(fb_qnet *h, int which, const uint8_t *states, int n) {
+    Plan p; memset(&p, 0, sizeof(p));
+    p.sl.s[0] = Slice{h->params[which], states, 0, n};
+    p.ns = 1;
+    return p;
 }
 
 extern "C" int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream) {
     FB_REQUIRE(h && states && q && (which == 0 || which == 1), "fb_qnet_forward: bad argument");
     FB_REQUIRE(batch >= 1 && batch <= 3 * h->max_batch, "fb_qnet_forward: batch %d exceeds 3*max_batch", batch);
-    Slices sl; memset(&sl, 0, sizeof(sl));
-    sl.s[0] = Slice{h->params[which], states, 0, batch};
-    int rc = run_forward(h, sl, 1, fb_stream(stream), nullptr, 0.f, 0, 0);
+    int rc = run_plan(h, forward_plan(h, which, states, batch), -1, fb_stream(stream));
     if (rc != FB_OK) return rc;
     FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)batch * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
     return FB_OK;
@@ -755,9 +811,9 @@ extern "C" int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsi
                            uint8_t *actions, float *q, void *stream) {
     FB_REQUIRE(h && states && actions, "fb_qnet_act: NULL argument");
     FB_REQUIRE(n >= 1 && n <= 3 * h->max_batch, "fb_qnet_act: n %d exceeds 3*max_batch", n);
-    Slices sl; memset(&sl, 0, sizeof(sl));
-    sl.s[0] = Slice{h->params[0], states, 0, n};
-    int rc = run_forward(h, sl, 1, fb_stream(stream), actions, epsilon, seed, step);
+    Plan p = forward_plan(h, 0, states, n);
+    p.actions = actions; p.epsilon = epsilon; p.seed = seed; p.step = step;
+    int rc = run_plan(h, p, -1, fb_stream(stream));
     if (rc != FB_OK) return rc;
     if (q) FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)n * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
     return FB_OK;
@@ -778,52 +834,60 @@ extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     return FB_OK;
 }
 
-extern "C" int fb_qnet_train_step(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r,
-                                  const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
-                                  float *abs_err, float *q_target, float *flat_grad, void *stream) {
+static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
+                      const uint8_t *t, const float *isw, double gamma, float *loss, float *abs_err, float *q_target,
+                      float *flat_grad, Plan *out) {
     FB_REQUIRE(h && s && a && r && s2 && t && loss, "fb_qnet_train_step: NULL argument");
     FB_REQUIRE(algo >= 0 && algo <= 3, "fb_qnet_train_step: unknown algo %d", algo);
     FB_REQUIRE(B >= 1 && B <= h->max_batch && B <= MAXTB, "fb_qnet_train_step: batch %d exceeds min(max_batch, %d)", B, MAXTB);
     FB_REQUIRE(algo != FB_ALGO_PER || isw, "fb_qnet_train_step: PER needs isw");
-    hipStream_t st = fb_stream(stream);
-    float *G = flat_grad ? flat_grad : h->grad;
-    // ---- forward: s through the online net, s' through the net(s) the algorithm asks for
-    Slices sl; memset(&sl, 0, sizeof(sl));
-    int ns = 2;
-    sl.s[0] = Slice{h->params[0], s, 0, B};
-    if (algo == FB_ALGO_DQN) sl.s[1] = Slice{h->params[0], s2, B, B};                 // BrainDQN.py:205 (same net)
-    else if (algo == FB_ALGO_DOUBLE) { sl.s[1] = Slice{h->params[0], s2, B, B}; sl.s[2] = Slice{h->params[1], s2, 2 * B, B}; ns = 3; }
-    else sl.s[1] = Slice{h->params[1], s2, B, B};                                     // target net
-    int rc = run_forward(h, sl, ns, st, nullptr, 0.f, 0, 0);
-    if (rc != FB_OK) return rc;
-    // ---- targets, loss, head backward
-    LossArgs L;
-    L.algo = algo; L.B = B; L.FC = h->FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
-    L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.act = a; L.rew = r; L.term = t; L.isw = isw; L.gamma = gamma;
-    L.grad = G; L.dhf = h->dhf; L.loss = loss; L.abs_err = abs_err; L.y_out = q_target; L.adam = h->adam;
-    L.tick = flat_grad == nullptr;
-    hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, st, L);
-    // ---- backward
-    const int FC = h->FC;
-    hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, st, h->h3, h->dhf, G, B, FC);
-    hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(256), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
-    int z3 = (B * 25 + 1023) / 1024, z2 = z3, z1 = (B * 400 + 1023) / 1024;           // >= 64 pixel pairs per wave
-    if (z3 > h->zmax) z3 = z2 = h->zmax;
-    if (z1 > h->zmax) z1 = h->zmax;
-    const size_t ss = CONV_PARAMS;
-    const ConvGeom g3{5, 5, 5, 5, 64, 64, 3, 1, 1}, g2{5, 5, 10, 10, 32, 64, 4, 2, 1}, g1{20, 20, 80, 80, 4, 32, 8, 4, 2};
-    hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(36, z3), dim3(512), 0, st, g3, B, h->h2, (const uint8_t *)nullptr, h->dh3,
-                       (const uint8_t *)nullptr, h->slabs, ss, OFF_W3);
-    hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
-    hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(32, z2), dim3(512), 0, st, g2, B, h->p1, (const uint8_t *)nullptr, h->dh2,
-                       (const uint8_t *)nullptr, h->slabs, ss, OFF_W2);
-    hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 100 + 31) / 32), dim3(512), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
-    hipLaunchKernelGGL(conv_dw_kernel<true>, dim3(8, z1), dim3(512), 0, st, g1, B, (const float *)nullptr, s, h->dp1, h->amax,
-                       h->slabs, ss, OFF_W1);
-    hipLaunchKernelGGL(conv_bias_kernel, dim3(3), dim3(256), 0, st, h->dh3, h->dh2, h->dp1, G, B);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
-    if (!flat_grad)
-        hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam);
-    FB_LAUNCH_CHECK();
+    Plan p; memset(&p, 0, sizeof(p));
+    // forward: s through the online net, s' through the net(s) the algorithm asks for
+    p.ns = 2;
+    p.sl.s[0] = Slice{h->params[0], s, 0, B};
+    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B};               // BrainDQN.py:205 (same net)
+    else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B}; p.ns = 3; }
+    else p.sl.s[1] = Slice{h->params[1], s2, B, B};                                   // target net
+    p.train = true; p.algo = algo; p.B = B; p.s = s; p.a = a; p.r = r; p.t = t; p.isw = isw; p.gamma = gamma;
+    p.loss = loss; p.abs_err = abs_err; p.y = q_target;
+    p.G = flat_grad ? flat_grad : h->grad;
+    p.apply_adam = flat_grad == nullptr; p.tick = flat_grad == nullptr;
+    *out = p;
     return FB_OK;
+}
+
+extern "C" int fb_qnet_train_step(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r,
+                                  const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
+                                  float *abs_err, float *q_target, float *flat_grad, void *stream) {
+    Plan p;
+    int rc = train_plan(h, algo, B, s, a, r, s2, t, isw, gamma, loss, abs_err, q_target, flat_grad, &p);
+    if (rc != FB_OK) return rc;
+    return run_plan(h, p, -1, fb_stream(stream));
+}
+
+// Measurement aid for bench.py: launch ONE kernel of the train-step plan (`kernel` = KernelId, see
+// fb_qnet_kernel_name) `reps` times with the real launch geometry.  It re-runs that kernel on the
+// workspace a preceding fb_qnet_train_step left behind; the Adam tick is disabled, and for K_ADAM
+// the step is applied `reps` times, so call it on a scratch network only.
+extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int algo, int B, const uint8_t *s, const uint8_t *a,
+                                      const float *r, const uint8_t *s2, const uint8_t *t, float *loss, void *stream) {
+    FB_REQUIRE(kernel >= 0 && kernel < K_COUNT && reps >= 1, "fb_qnet_profile_kernel: bad kernel id / reps");
+    Plan p;
+    int rc = FB_OK;
+    if (algo < 0) {                              // the acting forward: one slice of B states through the online net
+        FB_REQUIRE(h && s && B >= 1 && B <= 3 * h->max_batch && kernel <= K_HEAD, "fb_qnet_profile_kernel: bad forward request");
+        p = forward_plan(h, 0, s, B);
+    } else rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, 0.99, loss, nullptr, nullptr, nullptr, &p);
+    if (rc != FB_OK) return rc;
+    p.tick = false;
+    for (int i = 0; i < reps; i++) { rc = run_plan(h, p, kernel, fb_stream(stream)); if (rc != FB_OK) return rc; }
+    return FB_OK;
+}
+
+extern "C" const char *fb_qnet_kernel_name(int kernel) {
+    static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv2_kernel", "conv3_kernel", "fc1_kernel", "head_kernel",
+                                         "loss_head_kernel", "fc1_dw_kernel", "fc1_dx_kernel", "conv_dw_kernel<conv3>",
+                                         "conv3_dx_kernel", "conv_dw_kernel<conv2>", "conv2_dx_kernel", "conv_dw_kernel<conv1>",
+                                         "conv_bias_kernel", "slab_reduce_kernel", "adam_kernel"};
+    return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }
