@@ -78,6 +78,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FbError(f"{LIB_PATH} is missing: build it with `make -C dqnflappybird_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, same as /opt/rocm's).
+        # Import torch FIRST so that the process has ONE HIP runtime and libfbdqn.so binds to it;
+        # loading /opt/rocm's copy first leaves torch without devices ("No HIP GPUs are available").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError = stale library: rebuild it
