@@ -35,6 +35,7 @@ SIGNATURES = {
     "fb_env_set_gap_tape": [_vp, _vp, _i],
     "fb_env_render_full": [_vp, _i, _vp, _vp],
     "fb_env_error_count": [_vp, _vp],
+    "fb_preprocess_rgb": [_vp, _vp, _i, _vp, _vp],
     "fb_replay_create": [_i64, _i, _i, _vp],
     "fb_replay_destroy": [_vp],
     "fb_replay_seed": [_vp, _i, _u64],

@@ -235,6 +235,27 @@ __global__ __launch_bounds__(256) void render_full_kernel(EnvParams p, int env, 
     }
 }
 
+// preprocess() of FlappyBirdDQN.py:31-34 for arbitrary array3d frames u8[n][288][512][3]
+// (the fused env kernel never needs this; it is the drop-in for callers that hold RGB frames)
+__global__ __launch_bounds__(256) void preprocess_kernel(const EnvConst *__restrict__ cst, const uint8_t *__restrict__ rgb,
+                                                         int n, uint8_t *__restrict__ out) {
+    const EnvLds &T = cst->l;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)n * 6400; idx += (long long)gridDim.x * 256) {
+        const int f = (int)(idx / 6400), pix = (int)(idx - (long long)f * 6400), r = pix / OBS, c = pix - r * OBS;
+        const uint8_t *img = rgb + (size_t)f * SW * SH * 3;
+        const int x0 = T.xo[r], y0 = T.yo[c];
+        uint32_t s[2][2];
+#pragma unroll
+        for (int tx = 0; tx < 2; tx++)
+#pragma unroll
+            for (int ty = 0; ty < 2; ty++) {
+                const uint8_t *p = img + ((size_t)(x0 + tx) * SH + (y0 + ty)) * 3;
+                s[tx][ty] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            }
+        out[idx] = resize_gray_bit(s[0][0], s[0][1], s[1][0], s[1][1], T.ya0[c], T.ya1[c], T.xb0[r], T.xb1[r]) ? 255 : 0;
+    }
+}
+
 __global__ void env_reset_kernel(EnvParams p) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.n_envs) return;
@@ -409,6 +430,15 @@ extern "C" int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape
 extern "C" int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream) {
     FB_REQUIRE(h && rgb && env_id >= 0 && env_id < h->p.n_envs, "fb_env_render_full: bad argument");
     hipLaunchKernelGGL(render_full_kernel, dim3(144), dim3(256), 0, fb_stream(stream), h->p, env_id, rgb);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_preprocess_rgb(fb_env_t h, const uint8_t *rgb, int n_frames, uint8_t *out, void *stream) {
+    FB_REQUIRE(h && rgb && out && n_frames >= 1, "fb_preprocess_rgb: bad argument");
+    const long long total = (long long)n_frames * 6400;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, fb_stream(stream), h->d_const, rgb, n_frames, out);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

@@ -88,6 +88,10 @@ int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len);
 int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream);
 /* number of invalid actions seen so far (synchronous). */
 int fb_env_error_count(fb_env_t h, int64_t *count_host);
+/* preprocess() of FlappyBirdDQN.py:31-34 (cv2.resize -> BGR2GRAY -> threshold) for frames the caller
+ * holds as array3d images: rgb u8[n,288,512,3] [dev] -> out u8[n,80,80] [dev].  The fused env step
+ * never needs it; it exists so that `preprocess(observ)` stays a drop-in. */
+int fb_preprocess_rgb(fb_env_t h, const uint8_t *rgb, int n_frames, uint8_t *out, void *stream);
 
 /* ------------------------------------------------------------------ replay memory
  * HBM ring of single frames (1 bit / pixel: preprocess only emits 0 or 255) + per-transition

@@ -1,0 +1,112 @@
+"""A CPU stand-in for dqnflappybird_amd.backend.HipBackend, built on the oracle (tests only): lets the
+`-m "not gpu"` suite run the Brain classes' host logic (schedules, RNG order, API surface)."""
+import numpy as np
+
+from oracle import oracle as o
+
+
+class CpuNet:
+    def __init__(self, actions, fc_width, arch, max_batch):
+        self.cfg = o.qcfg(fc_width, actions, arch == "dueling")
+        self.n_params = o.nparams(self.cfg)
+        self.p = [np.zeros(self.n_params, np.float32), np.zeros(self.n_params, np.float32)]
+        self.opt = o.Adam(self.n_params)
+        self.syncs = 0
+        self.train_calls = []
+
+    def init_params(self, seed=0, which=0):
+        self.p[which] = o.init_params(self.cfg, seed)
+
+    def forward(self, states, which=0):
+        return o.forward(self.p[which], self.cfg, states)
+
+    def sync_target(self):
+        self.p[1] = self.p[0].copy()
+        self.syncs += 1
+
+    def train_step(self, algo, s, a, r, s2, t, isw=None, gamma=0.99, flat_grad=None, want_aux=True):
+        q, acts = o.forward(self.p[0], self.cfg, s, keep=True)
+        if algo == "dqn":
+            qn = o.forward(self.p[0], self.cfg, s2).max(1)
+        elif algo == "double":
+            am = o.forward(self.p[0], self.cfg, s2).argmax(1)
+            qn = o.forward(self.p[1], self.cfg, s2)[np.arange(len(am)), am]
+        else:
+            qn = o.forward(self.p[1], self.cfg, s2).max(1)
+        kind = {"dqn": 0, "nature": 1, "double": 1, "per": 2}[algo]
+        y, loss, ae, dq = o.dqn_loss(kind, q, qn, a, r, t, isw=None if isw is None else np.asarray(isw, np.float32), gamma=gamma)
+        g = o.backward(self.p[0], self.cfg, s, acts, dq)
+        self.train_calls.append(algo)
+        if flat_grad is None:
+            self.opt.step(self.p[0], g)
+        else:
+            flat_grad[...] = g
+        return np.float32(loss), ae, y
+
+    def apply_adam(self, g):
+        self.opt.step(self.p[0], g)
+
+
+class CpuReplay:
+    """deque semantics of BrainDQN.py:66-72 for one env (+ the oracle Memory for PER)."""
+
+    def __init__(self, capacity, prioritized):
+        self.cap, self.prioritized = capacity, prioritized
+        self.mem, self.state = [], None
+        self.per = o.Memory(capacity) if prioritized else None
+        self.slots = {}
+
+    def reset(self, frames):
+        f = np.asarray(frames).reshape(80, 80)
+        self.state = np.stack([f] * 4, axis=2)
+        self.mem = []
+
+    def push(self, frames, a, r, t):
+        new = np.append(self.state[:, :, 1:], np.asarray(frames).reshape(80, 80, 1), axis=2)
+        tr = (self.state, int(np.asarray(a)[0]), float(np.asarray(r)[0]), new, int(np.asarray(t)[0]))
+        if self.prioritized:
+            self.slots[self.per.data_pointer] = tr
+            self.per.store()
+        else:
+            self.mem.append(tr)
+            if len(self.mem) > self.cap:
+                self.mem.pop(0)
+        self.state = new
+
+    def sample(self, n, uniforms=None):
+        idx, isw = self.per.sample(n, u=np.asarray(uniforms))
+        return idx.astype(np.int64), isw
+
+    def gather(self, idx):
+        idx = np.asarray(idx)
+        trs = [self.slots[int(i) - (self.cap - 1)] for i in idx] if self.prioritized else [self.mem[int(i)] for i in idx]
+        s = np.stack([x[0] for x in trs]); s2 = np.stack([x[3] for x in trs])
+        return (s, np.array([x[1] for x in trs], np.uint8), np.array([x[2] for x in trs], np.float32), s2,
+                np.array([x[4] for x in trs], np.uint8))
+
+    def update_priorities(self, idx, abs_err=None, priorities=None):
+        if priorities is not None:
+            self.per.batch_update_p(np.asarray(idx, np.int32), priorities)
+        else:
+            self.per.batch_update(np.asarray(idx, np.int32), abs_err)
+
+    def per_state(self, want_tree=True):
+        return self.per.tree.copy(), self.per.data_pointer, self.per.size, self.per.beta
+
+
+class CpuBackend:
+    name = "cpu-oracle (tests only)"
+
+    def make_net(self, actions, fc_width, arch, max_batch):
+        return CpuNet(actions, fc_width, arch, max_batch)
+
+    def make_replay(self, capacity, prioritized):
+        return CpuReplay(capacity, prioritized)
+
+    @staticmethod
+    def dev(x, dtype=None):
+        return np.ascontiguousarray(x)
+
+    @staticmethod
+    def host(t):
+        return np.asarray(t)

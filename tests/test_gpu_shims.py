@@ -1,0 +1,126 @@
+"""The drop-in Python surface on the GPU: game.wrapped_flappy_bird.GameState, preprocess,
+Brain* classes (FlappyBirdDQN.py:36-76 loop) and the vectorised VecBrain loop."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("name,seed", [("traj0_never", 1), ("traj2_every7", 3), ("traj6_seek", 7)])
+def test_gamestate_dropin_reproduces_reference_with_python_random(torch_cuda, golden, name, seed):
+    """random.seed(s); GameState(); frame_step(one-hot)... == the reference's own module run with the
+    same seed: pipes come from `random` in the reference's order, so states/rewards match step by step."""
+    from dqnflappybird_amd.game import wrapped_flappy_bird as game
+    g = golden("game_trajectories.npz")
+    assert (game.SCREENWIDTH, game.SCREENHEIGHT, game.PIPE_WIDTH, game.PIPE_HEIGHT, game.PLAYER_WIDTH,
+            game.PLAYER_HEIGHT, game.PIPEGAPSIZE, game.FPS) == (288, 512, 52, 320, 34, 24, 100, 30)
+    assert abs(game.BASEY - 404.48) < 1e-12
+    random.seed(seed)
+    gs = game.GameState()
+    st = gs._env.get_state()
+    st[0, 13] = int(g[name + "_cyc0"][0])        # PLAYER_INDEX_GEN phase the fixture's process had
+    gs._env.set_state(st)
+    T = min(len(g[name + "_action"]), 400)
+    for t in range(T):
+        a = int(g[name + "_action"][t])
+        onehot = np.zeros(2)
+        onehot[a] = 1
+        img, r, term, score = gs.frame_step(onehot)
+        assert img.shape == (288, 512, 3) and img.dtype == np.uint8
+        assert r == pytest.approx(float(g[name + "_reward"][t])) and isinstance(r, (int, float))
+        assert term == bool(g[name + "_terminal"][t]) and score == g[name + "_score"][t]
+        want = g[name + "_state"][t + 1]
+        assert (gs.playery, gs.playerVelY, gs.playerIndex, gs.score) == (want[0], want[1], want[2], want[5])
+        assert [p["x"] for p in gs.upperPipes] == [x for x in want[7:10] if x != -9999]
+        assert [p["y"] for p in gs.upperPipes] == list(want[10:10 + want[6]])
+    # the global stream advanced exactly like the reference's: the next draw equals a twin's
+    nxt = random.random()
+    random.seed(seed)
+    for _ in range(len(g[name + "_draws"]) if T == len(g[name + "_action"]) else 0):
+        random.randint(0, 7)
+    if T == len(g[name + "_action"]):
+        assert nxt == random.random()
+    with pytest.raises(ValueError, match="Multiple input actions!"):
+        gs.frame_step(np.array([1, 1]))
+
+
+def test_preprocess_kernel_matches_oracle(torch_cuda, oracle):
+    from dqnflappybird_amd.FlappyBirdDQN import preprocess
+    env = oracle.GameState(seed=2)
+    for t in range(40):
+        env.step(int(t % 8 == 0))
+        if t % 5 == 0:
+            rgb = env.render_full()
+            out = preprocess(rgb)
+            assert out.shape == (80, 80, 1) and np.array_equal(out[:, :, 0], oracle.preprocess(rgb))
+    rng = np.random.default_rng(0)
+    noise = rng.integers(0, 256, (288, 512, 3), dtype=np.uint8)      # arbitrary image, not a game frame
+    assert np.array_equal(preprocess(noise)[:, :, 0], oracle.preprocess(noise))
+
+
+@pytest.mark.parametrize("model", ["dqn", "dqnnature", "ddqn", "duelingdqn", "prioritydqn"])
+def test_driver_loop_runs_every_model(torch_cuda, model):
+    """FlappyBirdDQN.py's loop end to end on the GPU for each --model (OBSERVE shortened)."""
+    from dqnflappybird_amd import FlappyBirdDQN as drv
+    cls = drv.model_class(model)
+    old = cls.OBSERVE
+    cls.OBSERVE = 40.
+    try:
+        random.seed(1)
+        np.random.seed(1)
+        brain = drv.playFlappyBird(model, steps=60, verbose=False)
+    finally:
+        cls.OBSERVE = old
+    assert brain.timeStep == 60 and len(brain) == 60
+    assert np.isfinite(brain.lost.item())
+    assert brain.currentState.shape == (80, 80, 4)
+    assert abs(brain.epsilon - (0.03 - 19 * 3e-8)) < 1e-12
+
+
+def test_brain_on_gpu_tracks_cpu_backend(torch_cuda, oracle):
+    """Same seeds, same frames: the HIP-backed BrainDQN and the oracle-backed one make the same
+    decisions and reach the same loss (first train steps)."""
+    from dqnflappybird_amd.BrainDQN import BrainDQN
+    from tests.cpu_backend import CpuBackend
+    from tests.test_brain_host_logic import frames_source
+    outs = []
+    for backend in (None, CpuBackend()):
+        first, step_env = frames_source(oracle, 9)
+        random.seed(5)
+        b = BrainDQN(2, 'bird', backend=backend, verbose=False, seed=3)
+        b.OBSERVE, b.BATCH_SIZE = 10., 8
+        if backend is None:
+            b.net.load_params(oracle.init_params(oracle.qcfg(), 3) * 3.0)
+        else:
+            b.net.p[0] = oracle.init_params(oracle.qcfg(), 3) * 3.0
+        b.setInitState(first)
+        acts, losses = [], []
+        for _ in range(16):
+            a = b.getAction()
+            obs, r, t, s = step_env(int(a[1]))
+            b.setPerception(obs, a, r, t, s)
+            acts.append(int(a[1]))
+            if b.lost is not None:
+                losses.append(float(b.lost.item() if hasattr(b.lost, "item") else b.lost))
+        outs.append((acts, losses))
+    assert outs[0][0] == outs[1][0]
+    np.testing.assert_allclose(outs[0][1][:2], outs[1][1][:2], rtol=1e-3)
+
+
+@pytest.mark.parametrize("algo", ["dqn", "nature", "per"])
+def test_vecbrain_device_resident_loop(torch_cuda, algo):
+    from dqnflappybird_amd.vecbrain import VecBrain
+    vb = VecBrain(64, algo=algo, capacity=20000, observe=5, seed=2)
+    vb.run(40, log_every=0)
+    assert vb.timeStep == 40 and len(vb.replay) == 40 * 64
+    assert np.isfinite(vb.last_loss.item())
+    assert int(vb.episodes.item()) >= 0
