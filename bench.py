@@ -192,8 +192,10 @@ def main():
             add(name + "[act n=1024]", us, 1, "mfma", FWD_FLOP[name] * N_ENVS)
         # train step, B = 32 (forward kernels see 2B samples: s and s')
         scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
-        for k in range(16):
+        for k in range(64):
             name = lib.fb_qnet_kernel_name(k).decode()
+            if not name:
+                break
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, 0, BATCH, L.ptr(s), L.ptr(a), L.ptr(r),
                                                                   L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
             if name in FWD_FLOP:

@@ -189,35 +189,48 @@ __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__re
     }
 }
 
-// fc1 1600xFC + bias + relu; 8 waves x 200 k
-__global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hf, int FC) {
+// fc1 1600xFC: the K = 1600 reduction is split over FC1_KS = 5 workgroups x 8 waves x 40 k, so every wave
+// issues its 40 operand loads at once and runs 20 MFMAs.  The 5 partial sums stay separate
+// (hfp[ks][sample][FC], no bias / relu yet): the two consumers (head_kernel, loss_head_kernel) add them in
+// a fixed order -- "reduce in the consumer's prologue" instead of one more launch.
+constexpr int FC1_KS = 5;
+
+__global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
+                                                  int stot) {
     __shared__ float red[7 * 16 * 64];
-    const Slice s = sl.s[blockIdx.z];
+    const int z = blockIdx.z / FC1_KS, ks = blockIdx.z - z * FC1_KS;
+    const Slice s = sl.s[z];
     const int M = s.count, tile = blockIdx.x, n0 = blockIdx.y * 32;
     if (tile * 32 >= M) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int m = tile * 32 + i;
     const bool ok = m < M;
-    const int k0 = wave * 200 + hl * 100;
+    const int k0 = ks * 320 + wave * 40 + hl * 20;
     const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
     const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
     f32x16 acc = {0};
-#pragma unroll 1
-    for (int c = 0; c < 5; c++) mma_run_col<20>(arun + 20 * c, ok, bcol + (size_t)20 * c * FC, FC, acc);
+    mma_run_col<20>(arun, ok, bcol, FC, acc);
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
-        const float bias = s.params[OFF_WF1 + 1600 * FC + n0 + j];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) hf[(size_t)(s.s_off + mr) * FC + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+            if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
         }
     }
 }
 
+// relu(bias + sum of the fc1 partials) for one (sample, unit)
+__device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot, int FC, int smp, int jj, float bias) {
+    float v = hfp[(size_t)smp * FC + jj];
+#pragma unroll
+    for (int ks = 1; ks < FC1_KS; ks++) v += hfp[((size_t)ks * stot + smp) * FC + jj];
+    return fmaxf(v + bias, 0.f);
+}
+
 // fc2 / dueling head (+ epsilon-greedy action for the acting path); one wave per sample
 struct HeadArgs {
-    Slices sl; int nslices; const float *hf; float *q; int FC, A, dueling; NetOff off;
+    Slices sl; int nslices; const float *hf; int stot; float *q; int FC, A, dueling; NetOff off;
     uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
 };
 
@@ -231,12 +244,11 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
         sidx -= H.sl.s[z].count;
     }
     if (smp < 0) return;
-    const float *h = H.hf + (size_t)smp * H.FC;
     float acc[MAXA + 1];
 #pragma unroll
     for (int a = 0; a <= MAXA; a++) acc[a] = 0.f;
     for (int jj = lane; jj < H.FC; jj += 64) {
-        const float x = h[jj];
+        const float x = fc1_out(H.hf, H.stot, H.FC, smp, jj, P[H.off.bf1 + jj]);
 #pragma unroll
         for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x, P[H.off.wq + jj * H.A + a], acc[a]);
         if (H.dueling) acc[MAXA] = fmaf(x, P[H.off.wv + jj], acc[MAXA]);
@@ -277,18 +289,23 @@ struct LossArgs {
     NetOff off;
     const float *params;            // online
     const float *q;                 // [3B][A] workspace
-    const float *hf;                // [.][FC], rows 0..B-1 = s through the online net
+    const float *hf; int stot;      // fc1 partials [FC1_KS][stot][FC]; rows 0..B-1 = s through the online net
     const uint8_t *act; const float *rew; const uint8_t *term; const float *isw;
     double gamma;
     float *grad, *dhf, *loss, *abs_err, *y_out;
     AdamDev *adam; int tick;
 };
 
+// grid = FC / 64 workgroups.  Every workgroup recomputes the B targets (cheap), workgroup 0 also publishes
+// loss / abs_err / y, the output-bias gradients and the Adam tick.  Thread (jl, bg) owns unit j and every
+// 4th sample; the 4 partial sums per unit are added in a fixed order.
 __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     __shared__ float dadv[MAXTB][MAXA];
     __shared__ float dv[MAXTB];
     __shared__ float lterm[MAXTB];
+    __shared__ float part[4][64][MAXA + 2];
     const int tid = threadIdx.x, B = L.B, A = L.A;
+    const bool lead = blockIdx.x == 0;
     if (tid < B) {
         const float *qs = L.q + (size_t)tid * A;
         const float *qn = L.q + (size_t)(B + tid) * A;          // DQN: online(s'); Nature/PER: target(s'); Double: online(s')
@@ -310,8 +327,8 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
         const float d = y - qs[a_b];                             // q_eval = reduce_sum(Q * onehot)
         const float w = L.algo == FB_ALGO_PER ? L.isw[tid] : 1.f;
         lterm[tid] = w * d * d;
-        if (L.abs_err) L.abs_err[tid] = fabsf(d);
-        if (L.y_out) L.y_out[tid] = y;
+        if (lead && L.abs_err) L.abs_err[tid] = fabsf(d);
+        if (lead && L.y_out) L.y_out[tid] = y;
         const float scale = L.algo == FB_ALGO_DQN ? 2.f : 2.f / (float)B;     // sum vs mean
         const float g = -scale * w * d;                          // dLoss/dQ[b][a_b]
         if (L.dueling) {
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (lead && tid == 0) {
         float s = 0.f;
         for (int b = 0; b < B; b++) s += lterm[b];
         *L.loss = L.algo == FB_ALGO_DQN ? s : s / (float)B;
@@ -333,29 +350,35 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
             ad.b1pow *= ad.b1; ad.b2pow *= ad.b2;
         }
     }
+    if (lead && tid >= 64 && tid < 64 + A) { const int a = tid - 64; float s = 0.f; for (int b = 0; b < B; b++) s += dadv[b][a]; L.grad[L.off.bq + a] = s; }
+    if (lead && tid == 128 && L.dueling) { float s = 0.f; for (int b = 0; b < B; b++) s += dv[b]; L.grad[L.off.bv] = s; }
     const float *P = L.params;
-    for (int jj = tid; jj < L.FC; jj += 256) {
-        float gw[MAXA], wrow[MAXA], gv = 0.f, gb = 0.f;
+    const int jl = tid & 63, bg = tid >> 6, jj = blockIdx.x * 64 + jl;
+    float gw[MAXA], wrow[MAXA], gv = 0.f, gb = 0.f;
 #pragma unroll
-        for (int a = 0; a < MAXA; a++) { gw[a] = 0.f; wrow[a] = a < A ? P[L.off.wq + jj * A + a] : 0.f; }
-        const float wvj = L.dueling ? P[L.off.wv + jj] : 0.f;
-        for (int b = 0; b < B; b++) {
-            const float h = L.hf[(size_t)b * L.FC + jj];
-            float d = dv[b] * wvj;
+    for (int a = 0; a < MAXA; a++) { gw[a] = 0.f; wrow[a] = a < A ? P[L.off.wq + jj * A + a] : 0.f; }
+    const float wvj = L.dueling ? P[L.off.wv + jj] : 0.f, bias = P[L.off.bf1 + jj];
+    for (int b = bg; b < B; b += 4) {
+        const float h = fc1_out(L.hf, L.stot, L.FC, b, jj, bias);
+        float d = dv[b] * wvj;
 #pragma unroll
-            for (int a = 0; a < MAXA; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
-            gv = fmaf(h, dv[b], gv);
-            const float dh = h > 0.f ? d : 0.f;
-            L.dhf[(size_t)b * L.FC + jj] = dh;
-            gb += dh;
-        }
-#pragma unroll
-        for (int a = 0; a < MAXA; a++) if (a < A) L.grad[L.off.wq + jj * A + a] = gw[a];
-        if (L.dueling) L.grad[L.off.wv + jj] = gv;
-        L.grad[L.off.bf1 + jj] = gb;
+        for (int a = 0; a < MAXA; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
+        gv = fmaf(h, dv[b], gv);
+        const float dh = h > 0.f ? d : 0.f;
+        L.dhf[(size_t)b * L.FC + jj] = dh;
+        gb += dh;
     }
-    if (tid < A) { float s = 0.f; for (int b = 0; b < B; b++) s += dadv[b][tid]; L.grad[L.off.bq + tid] = s; }
-    if (tid == A && L.dueling) { float s = 0.f; for (int b = 0; b < B; b++) s += dv[b]; L.grad[L.off.bv] = s; }
+#pragma unroll
+    for (int a = 0; a < MAXA; a++) part[bg][jl][a] = gw[a];
+    part[bg][jl][MAXA] = gv; part[bg][jl][MAXA + 1] = gb;
+    __syncthreads();
+    if (bg == 0) {
+#pragma unroll
+        for (int a = 0; a < MAXA; a++)
+            if (a < A) L.grad[L.off.wq + jj * A + a] = ((part[0][jl][a] + part[1][jl][a]) + part[2][jl][a]) + part[3][jl][a];
+        if (L.dueling) L.grad[L.off.wv + jj] = ((part[0][jl][MAXA] + part[1][jl][MAXA]) + part[2][jl][MAXA]) + part[3][jl][MAXA];
+        L.grad[L.off.bf1 + jj] = ((part[0][jl][MAXA + 1] + part[1][jl][MAXA + 1]) + part[2][jl][MAXA + 1]) + part[3][jl][MAXA + 1];
+    }
 }
 
 __global__ void adam_tick_kernel(AdamDev *ad) {
@@ -383,20 +406,22 @@ __global__ __launch_bounds__(256) void fc1_dw_kernel(const float *__restrict__ h
     for (int r = 0; r < 16; r++) grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + j] = acc[r];
 }
 
-// dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 4 waves split n
-__global__ __launch_bounds__(256) void fc1_dx_kernel(const float *__restrict__ params, const float *__restrict__ h3,
+// dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 8 waves split n
+__global__ __launch_bounds__(512) void fc1_dx_kernel(const float *__restrict__ params, const float *__restrict__ h3,
                                                      const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC) {
-    __shared__ float red[3 * 16 * 64];
+    __shared__ float red[7 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int mt = blockIdx.x, kt = blockIdx.y;
     const int m = mt * 32 + i;
     const bool ok = m < B;
-    const int kh = FC / 8, nbeg = wave * (FC / 4) + hl * kh;
+    const int kh = FC / 16, nbeg = wave * (FC / 8) + hl * kh;
     const float *arun = dhf + (size_t)(ok ? m : 0) * FC + nbeg;
     const float *brun = params + OFF_WF1 + (size_t)(kt * 32 + j) * FC + nbeg;
     f32x16 acc = {0};
-    for (int c = 0; c < kh; c += 16) mma_run_run<16>(arun + c, ok, brun + c, acc);
-    reduce_waves<4>(acc, red, wave, lane);
+    int c = 0;
+    for (; c + 32 <= kh; c += 32) mma_run_run<32>(arun + c, ok, brun + c, acc);
+    for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc);
+    reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -409,60 +434,74 @@ __global__ __launch_bounds__(256) void fc1_dx_kernel(const float *__restrict__ p
     }
 }
 
-// generic conv weight gradient: dW[(cell, ci)][co] = sum_m X[m @ cell][ci] * dY[m][co].
-// One workgroup = one 32(ci) x 32(co) tile of one kernel cell; its 8 waves (and gridDim.y slabs)
-// split the reduction over output pixels m.
-struct ConvGeom { int OH, OW, IH, IW, CI, CO, K, stride, pad; };
+// conv weight (+ bias) gradients: dW[(cell, ci)][co] = sum_m X[m @ cell][ci] * dY[m][co], db[co] = sum_m dY[m][co].
+// One workgroup = one 32(ci) x 32(co) tile of one kernel cell; its 8 waves and the gridDim.y slabs split
+// the reduction over output pixels m (each wave: one or two chunks of 16 MFMAs whose 32 operand loads are
+// all issued before the first MFMA).  The last CO/32 workgroups of a launch are "bias tiles": their A
+// operand is 1 in row 0, so row 0 of the tile is the column sum of dY.  Slabs are summed by
+// slab_reduce_kernel in a fixed order.
+template <int LAYER> struct DwGeom;
+template <> struct DwGeom<1> { static constexpr int OH = 20, OW = 20, IH = 80, IW = 80, CI = 4, CO = 32, K = 8, S = 4, P = 2, WOFF = OFF_W1, BOFF = OFF_B1, CELLS = 8, CIT = 1; };
+template <> struct DwGeom<2> { static constexpr int OH = 5, OW = 5, IH = 10, IW = 10, CI = 32, CO = 64, K = 4, S = 2, P = 1, WOFF = OFF_W2, BOFF = OFF_B2, CELLS = 16, CIT = 1; };
+template <> struct DwGeom<3> { static constexpr int OH = 5, OW = 5, IH = 5, IW = 5, CI = 64, CO = 64, K = 3, S = 1, P = 1, WOFF = OFF_W3, BOFF = OFF_B3, CELLS = 9, CIT = 2; };
 
-template <bool CONV1>
-__global__ __launch_bounds__(512) void conv_dw_kernel(ConvGeom G, int B, const float *__restrict__ x,
-                                                      const uint8_t *__restrict__ xu8, const float *__restrict__ dy,
-                                                      const uint8_t *__restrict__ amax, float *__restrict__ out,
-                                                      size_t slab_stride, int w_off) {
+template <int LAYER>
+__global__ __launch_bounds__(512) void conv_dw_kernel(int B, const float *__restrict__ x, const uint8_t *__restrict__ xu8,
+                                                      const float *__restrict__ dy, const uint8_t *__restrict__ amax,
+                                                      float *__restrict__ slabs, size_t slab_stride) {
+    using G = DwGeom<LAYER>;
+    constexpr int COT = G::CO / 32, WTILES = G::CELLS * G::CIT * COT, OPIX = G::OH * G::OW;
     __shared__ float red[7 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int co_tiles = G.CO / 32;
-    int tile = blockIdx.x;
-    const int cot = tile % co_tiles; tile /= co_tiles;
-    // conv1: a "cell" is one kernel row ky with the 32 (kx, f) taps as the tile's 32 ci rows
-    const int ci_tiles = CONV1 ? 1 : G.CI / 32;
-    const int cit = tile % ci_tiles; const int cell = tile / ci_tiles;
-    const int ky = CONV1 ? cell : cell / G.K, kx = CONV1 ? 0 : cell - ky * G.K;
-    const int opix = G.OH * G.OW, M = B * opix;
-    const int parts = gridDim.y * 8;
+    const bool bias_tile = (int)blockIdx.x >= WTILES;
+    int tile = bias_tile ? 0 : blockIdx.x;
+    const int cot = bias_tile ? (int)blockIdx.x - WTILES : tile % COT;
+    tile /= COT;
+    const int cit = tile % G::CIT, cell = tile / G::CIT;
+    const int ky = LAYER == 1 ? cell : cell / G::K, kx = LAYER == 1 ? 0 : cell - ky * G::K;
+    const int M = B * OPIX, parts = gridDim.y * 8;
     int per = (M + parts - 1) / parts; per += per & 1;
     const int mbeg = (blockIdx.y * 8 + wave) * per;
     const int mend = mbeg + per < M ? mbeg + per : M;
     f32x16 acc = {0};
-#pragma unroll 2
-    for (int mm = mbeg; mm < mend; mm += 2) {
-        const int m = mm + hl;
-        float a = 0.f, bb = 0.f;
-        if (m < mend) {
-            const int b = m / opix, rem = m - b * opix, oy = rem / G.OW, ox = rem - oy * G.OW;
-            const int iy = oy * G.stride + ky - G.pad;
-            if (CONV1) {
-                const int ix = ox * 4 - 2 + (i >> 2);
-                if (iy >= 0 && iy < 80 && ix >= 0 && ix < 80)
-                    a = (float)xu8[(((size_t)b * 80 + iy) * 80 + ix) * 4 + (i & 3)];
-                const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
-                if (amax[po] == ((oy & 1) * 2 + (ox & 1))) bb = dy[po];       // max_pool routes to the arg max
-            } else {
-                const int ix = ox * G.stride + kx - G.pad;
-                if (iy >= 0 && iy < G.IH && ix >= 0 && ix < G.IW)
-                    a = x[(((size_t)b * G.IH + iy) * G.IW + ix) * G.CI + cit * 32 + i];
-                bb = dy[(size_t)m * G.CO + cot * 32 + j];
+    for (int c0 = mbeg; c0 < mend; c0 += 32) {
+        float a[16], bb[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int m = c0 + 2 * t + hl;
+            a[t] = 0.f; bb[t] = 0.f;
+            if (m < mend) {
+                const int b = m / OPIX, rem = m - b * OPIX, oy = rem / G::OW, ox = rem - oy * G::OW;
+                const int iy = oy * G::S + ky - G::P;
+                if (LAYER == 1) {
+                    const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
+                    if (amax[po] == ((oy & 1) * 2 + (ox & 1))) bb[t] = dy[po];       // max_pool routes to the arg max
+                    const int ix = ox * 4 - 2 + (i >> 2);
+                    if (bias_tile) a[t] = i == 0 ? 1.f : 0.f;
+                    else if (iy >= 0 && iy < 80 && ix >= 0 && ix < 80) a[t] = (float)xu8[(((size_t)b * 80 + iy) * 80 + ix) * 4 + (i & 3)];
+                } else {
+                    bb[t] = dy[(size_t)m * G::CO + cot * 32 + j];
+                    const int ix = ox * G::S + kx - G::P;
+                    if (bias_tile) a[t] = i == 0 ? 1.f : 0.f;
+                    else if (iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW)
+                        a[t] = x[(((size_t)b * G::IH + iy) * G::IW + ix) * G::CI + cit * 32 + i];
+                }
             }
         }
-        acc = mfma(a, bb, acc);
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = mfma(a[t], bb[t], acc);
     }
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
-        float *o = out + blockIdx.y * slab_stride + w_off;
+        float *o = slabs + blockIdx.y * slab_stride;
+        if (bias_tile) {
+            if (hl == 0) o[G::BOFF + cot * 32 + j] = acc[0];                         // row 0 = column sums
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = CONV1 ? (ky * 32 + drow(r, lane)) : (cell * G.CI + cit * 32 + drow(r, lane));
-            o[(size_t)row * G.CO + cot * 32 + j] = acc[r];
+            for (int r = 0; r < 16; r++) {
+                const int row = LAYER == 1 ? (ky * 32 + drow(r, lane)) : (cell * G::CI + cit * 32 + drow(r, lane));
+                o[G::WOFF + (size_t)row * G::CO + cot * 32 + j] = acc[r];
+            }
         }
     }
 }
@@ -518,28 +557,12 @@ __global__ __launch_bounds__(512) void conv2_dx_kernel(const float *__restrict__
     }
 }
 
-// conv bias gradients: column sums of dh3 (64), dh2 (64), dp1 (32); one workgroup each
-__global__ __launch_bounds__(256) void conv_bias_kernel(const float *__restrict__ dh3, const float *__restrict__ dh2,
-                                                        const float *__restrict__ dp1, float *__restrict__ grad, int B) {
-    __shared__ float part[256];
-    const int which = blockIdx.x, tid = threadIdx.x;
-    const float *src = which == 0 ? dh3 : (which == 1 ? dh2 : dp1);
-    const int C = which == 2 ? 32 : 64, M = which == 2 ? B * 100 : B * 25, off = which == 0 ? OFF_B3 : (which == 1 ? OFF_B2 : OFF_B1);
-    const int c = tid % C, p = tid / C, np = 256 / C;
-    float s = 0.f;
-    for (int m = p; m < M; m += np) s += src[(size_t)m * C + c];
-    part[tid] = s;
-    __syncthreads();
-    if (tid < C) { float t = 0.f; for (int q = 0; q < np; q++) t += part[q * C + tid]; grad[off + tid] = t; }
-}
-
-// sum the reduction slabs of the conv weight gradients into the flat gradient (fixed order)
+// sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
                                    float *__restrict__ grad) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= CONV_PARAMS) return;
-    int z;
-    if (idx < OFF_B1) z = z1; else if (idx >= OFF_W2 && idx < OFF_B2) z = z2; else if (idx >= OFF_W3 && idx < OFF_B3) z = z3; else return;
+    const int z = idx < OFF_W2 ? z1 : (idx < OFF_W3 ? z2 : z3);
     float s = 0.f;
     for (int q = 0; q < z; q++) s += slabs[q * slab_stride + idx];
     grad[idx] = s;
@@ -632,7 +655,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
-    alloc((void **)&h->hf, S * fc_width * 4); alloc((void **)&h->q, S * MAXA * 4);
+    alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
     const size_t Bm = max_batch;
     alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
     alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
@@ -728,7 +751,7 @@ extern "C" int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *
 // step uses.  `only` < 0 launches the whole plan.
 enum KernelId {
     K_CONV1 = 0, K_CONV2, K_CONV3, K_FC1, K_HEAD, K_LOSS, K_FC1_DW, K_FC1_DX, K_CONV3_DW, K_CONV3_DX, K_CONV2_DW,
-    K_CONV2_DX, K_CONV1_DW, K_BIAS, K_SLAB, K_ADAM, K_COUNT
+    K_CONV2_DX, K_CONV1_DW, K_SLAB, K_ADAM, K_COUNT
 };
 
 struct Plan {
@@ -746,10 +769,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     FB_K(K_CONV1) hipLaunchKernelGGL(conv1_pool_kernel, dim3((maxc * 100 + 7) / 8, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
     FB_K(K_CONV2) hipLaunchKernelGGL(conv2_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
     FB_K(K_CONV3) hipLaunchKernelGGL(conv3_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
-    FB_K(K_FC1) hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC);
+    const int stot = 3 * h->max_batch;
+    FB_K(K_FC1) hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
     FB_K(K_HEAD) {
         HeadArgs H;
-        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.q = h->q; H.FC = h->FC; H.A = h->A;
+        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.q = h->q; H.FC = h->FC; H.A = h->A;
         H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
         H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
         H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
@@ -761,27 +785,27 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         FB_K(K_LOSS) {
             LossArgs L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
-            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
+            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
             L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             L.adam = h->adam; L.tick = p.tick;
-            hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, st, L);
+            hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
         }
         FB_K(K_FC1_DW) hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, st, h->h3, h->dhf, G, B, FC);
-        FB_K(K_FC1_DX) hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(256), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
-        int z3 = (B * 25 + 1023) / 1024, z2 = z3, z1 = (B * 400 + 1023) / 1024;       // >= 64 pixel pairs per wave
-        if (z3 > h->zmax) z3 = z2 = h->zmax;
+        FB_K(K_FC1_DX) hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(512), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
+        // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
+        int z3 = (B * 25 + 255) / 256, z1 = (B * 400 + 255) / 256;
+        if (z3 > h->zmax) z3 = h->zmax;
         if (z1 > h->zmax) z1 = h->zmax;
+        const int z2 = z3;
         const size_t ss = CONV_PARAMS;
-        const ConvGeom g3{5, 5, 5, 5, 64, 64, 3, 1, 1}, g2{5, 5, 10, 10, 32, 64, 4, 2, 1}, g1{20, 20, 80, 80, 4, 32, 8, 4, 2};
-        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(36, z3), dim3(512), 0, st, g3, B, h->h2, (const uint8_t *)nullptr,
-                                            h->dh3, (const uint8_t *)nullptr, h->slabs, ss, OFF_W3);
+        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<3>, dim3(36 + 2, z3), dim3(512), 0, st, B, h->h2, (const uint8_t *)nullptr,
+                                            h->dh3, (const uint8_t *)nullptr, h->slabs, ss);
         FB_K(K_CONV3_DX) hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
-        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<false>, dim3(32, z2), dim3(512), 0, st, g2, B, h->p1, (const uint8_t *)nullptr,
-                                            h->dh2, (const uint8_t *)nullptr, h->slabs, ss, OFF_W2);
+        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<2>, dim3(32 + 2, z2), dim3(512), 0, st, B, h->p1, (const uint8_t *)nullptr,
+                                            h->dh2, (const uint8_t *)nullptr, h->slabs, ss);
         FB_K(K_CONV2_DX) hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 100 + 31) / 32), dim3(512), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
-        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv_dw_kernel<true>, dim3(8, z1), dim3(512), 0, st, g1, B, (const float *)nullptr, p.s, h->dp1,
-                                            h->amax, h->slabs, ss, OFF_W1);
-        FB_K(K_BIAS) hipLaunchKernelGGL(conv_bias_kernel, dim3(3), dim3(256), 0, st, h->dh3, h->dh2, h->dp1, G, B);
+        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv_dw_kernel<1>, dim3(8 + 1, z1), dim3(512), 0, st, B, (const float *)nullptr, p.s, h->dp1,
+                                            h->amax, h->slabs, ss);
         FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
             hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam);
@@ -888,6 +912,6 @@ extern "C" const char *fb_qnet_kernel_name(int kernel) {
     static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv2_kernel", "conv3_kernel", "fc1_kernel", "head_kernel",
                                          "loss_head_kernel", "fc1_dw_kernel", "fc1_dx_kernel", "conv_dw_kernel<conv3>",
                                          "conv3_dx_kernel", "conv_dw_kernel<conv2>", "conv2_dx_kernel", "conv_dw_kernel<conv1>",
-                                         "conv_bias_kernel", "slab_reduce_kernel", "adam_kernel"};
+                                         "slab_reduce_kernel", "adam_kernel"};
     return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }

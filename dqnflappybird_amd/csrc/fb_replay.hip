@@ -78,21 +78,26 @@ __global__ __launch_bounds__(64) void push_kernel(ReplayParams P, const uint8_t 
                                                   const unsigned long long *__restrict__ fbits,
                                                   const uint8_t *__restrict__ a, const float *__restrict__ r,
                                                   const uint8_t *__restrict__ t) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const long long steps = P.dev->steps;               // transition index this push writes
-    unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
-    if (fbits) {
-        for (int w = lane; w < WORDS; w += 64) dst[w] = fbits[(size_t)e * WORDS + w];
-    } else {
-        for (int w = 0; w < WORDS; w++) {
-            const unsigned long long m = __ballot(frames[(size_t)e * 6400 + w * 64 + lane] != 0);
-            if (lane == 0) dst[w] = m;
+    for (int e = blockIdx.x; e < P.n_envs; e += gridDim.x) {
+        unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
+        if (fbits) {
+            for (int w = lane; w < WORDS; w += 64) dst[w] = fbits[(size_t)e * WORDS + w];
+        } else {
+            for (int w = 0; w < WORDS; w++) {
+                const unsigned long long m = __ballot(frames[(size_t)e * 6400 + w * 64 + lane] != 0);
+                if (lane == 0) dst[w] = m;
+            }
+        }
+        if (lane == 0) {
+            const size_t mo = (size_t)(steps % P.t_f) * P.n_envs + e;
+            P.act[mo] = a[e]; P.rew[mo] = r[e]; P.term[mo] = t[e];
         }
     }
     if (lane == 0) {
-        const size_t mo = (size_t)(steps % P.t_f) * P.n_envs + e;
-        P.act[mo] = a[e]; P.rew[mo] = r[e]; P.term[mo] = t[e];
-        // the last workgroup to get here publishes the step (every workgroup read `steps` above)
+        // the last workgroup to get here publishes the step (every workgroup read `steps` above);
+        // at most 256 workgroups, so the single counter is touched at most 256 times per push
         __threadfence();
         const unsigned int prev = atomicAdd(&P.dev->done_ctr, 1u);
         if (prev == gridDim.x - 1) { P.dev->done_ctr = 0; P.dev->steps = steps + 1; }
@@ -557,7 +562,7 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
     FB_REQUIRE((frames != nullptr) != (frame_bits != nullptr), "fb_replay_push: give exactly one of frames / frame_bits");
     ReplayParams &P = h->P;
     hipStream_t st = fb_stream(stream);
-    hipLaunchKernelGGL(push_kernel, dim3(P.n_envs), dim3(64), 0, st, P, frames, (const unsigned long long *)frame_bits,
+    hipLaunchKernelGGL(push_kernel, dim3(P.n_envs < 256 ? P.n_envs : 256), dim3(64), 0, st, P, frames, (const unsigned long long *)frame_bits,
                        actions, rewards, terminals);
     FB_LAUNCH_CHECK();
     if (P.kind == FB_REPLAY_PER) {

@@ -192,8 +192,8 @@ int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream);
 int fb_qnet_sync_target(fb_qnet_t h, void *stream);
 /* Measurement aid (bench.py roofline): re-launch ONE kernel of the train-step plan `reps` times on
  * `stream` with the geometry the real step uses, on the workspace a preceding fb_qnet_train_step
- * of the same shape left behind.  kernel ids 0..15, names from fb_qnet_kernel_name().  Kernel 15
- * (Adam) really updates the parameters: use a scratch network. */
+ * of the same shape left behind.  Kernel ids count from 0; fb_qnet_kernel_name() returns "" past the
+ * last one.  The Adam kernel really updates the parameters: use a scratch network. */
 int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int algo, int batch, const uint8_t *s, const uint8_t *a,
                            const float *r, const uint8_t *s2, const uint8_t *t, float *loss, void *stream);
 const char *fb_qnet_kernel_name(int kernel);

@@ -68,7 +68,12 @@ def oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw):
 def test_train_step_gradients_match_oracle(torch_cuda, oracle, algo, dueling, B):
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet
-    rng = np.random.default_rng(hash((algo, dueling, B)) % 2 ** 31)
+    # fixed data per case (zlib.crc32, not the per-process str hash).  A gradient check through ReLUs is
+    # only meaningful away from the kinks: with other data one of the 51 200 conv activations per layer
+    # can sit within 1e-7 of zero, the fp32 device and the fp64-accumulating oracle then disagree on
+    # its mask and that unit's whole gradient column differs (seen once: conv2 channel 18, PYTHONHASHSEED=2).
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{algo}-{dueling}-{B}".encode()))
     cfg = oracle.qcfg(512, 2, dueling)
     p_on, p_tg = trained_like_params(oracle, cfg, 1), trained_like_params(oracle, cfg, 2)
     net = QNet(2, 512, "dueling" if dueling else "plain", max_batch=64)
