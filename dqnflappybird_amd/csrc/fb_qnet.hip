@@ -16,6 +16,7 @@
 // reduction dimension and are summed through LDS in a fixed order, so every result is bit
 // reproducible (no atomics anywhere).  DESIGN.md "Q-network kernels" has the tile tables.
 #include <math.h>
+#include <stdlib.h>
 #include "fb_common.h"
 
 namespace {
@@ -29,7 +30,7 @@ constexpr int MAXA = 8, MAXTB = 256;
 
 struct NetOff { int bf1, wv, bv, wq, bq, n; };
 
-struct Slice { const float *params; const uint8_t *states; int s_off, count; };
+struct Slice { const float *params; const uint8_t *states; int s_off, count; const uint16_t *w1s; };
 struct Slices { Slice s[3]; };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -88,55 +89,6 @@ __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool
 }
 
 // ================================================================== forward
-// conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2.  Tile rows = 8 pooled pixels x 4
-// window positions, so the pool is a max over 4 accumulator registers of one lane.
-__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
-    __shared__ float red[3 * 16 * 64];
-    const Slice s = sl.s[blockIdx.z];
-    const int npool = s.count * 100, tile = blockIdx.x;
-    if (tile * 8 >= npool) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int ky = 2 * wave + hl;
-    const int P = tile * 8 + (i >> 2), pos = i & 3;
-    const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
-    const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
-    const int iy = oy * 4 + ky - 2;
-    const bool rowok = P < npool && iy >= 0 && iy < 80;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(s.states) + ((size_t)b * 80 + (rowok ? iy : 0)) * 80;
-    float a[32];
-#pragma unroll
-    for (int kx = 0; kx < 8; kx++) {
-        const int ix = ox * 4 + kx - 2;
-        uint32_t v = 0;
-        if (rowok && ix >= 0 && ix < 80) v = src[ix];
-        a[4 * kx] = (float)(v & 255u); a[4 * kx + 1] = (float)((v >> 8) & 255u);
-        a[4 * kx + 2] = (float)((v >> 16) & 255u); a[4 * kx + 3] = (float)(v >> 24);
-    }
-    const float *W = s.params + OFF_W1 + (ky * 32) * 32 + j;
-    f32x16 acc = {0};
-#pragma unroll
-    for (int t = 0; t < 32; t++) acc = mfma(a[t], W[t * 32], acc);
-    reduce_waves<4>(acc, red, wave, lane);
-    if (wave == 0) {
-        const float bias = s.params[OFF_B1 + j];
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float bv = fmaxf(acc[4 * g] + bias, 0.f);
-            int best = 0;
-#pragma unroll
-            for (int q = 1; q < 4; q++) {
-                const float v = fmaxf(acc[4 * g + q] + bias, 0.f);
-                if (v > bv) { bv = v; best = q; }
-            }
-            const int Pp = tile * 8 + 2 * g + hl;
-            if (Pp < npool) {
-                const size_t o = ((size_t)s.s_off * 100 + Pp) * 32 + j;
-                p1[o] = bv; amax[o] = (uint8_t)best;
-            }
-        }
-    }
-}
-
 // conv2 4x4x32->64 stride 2 SAME(1,1) + bias + relu; 8 waves = 16 kernel cells / 2
 __global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
     __shared__ float red[7 * 16 * 64];
@@ -189,6 +141,186 @@ __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__re
     }
 }
 
+// ---- conv1 on the bf16 matrix cores, exactly.
+// conv1's input is u8 (in practice 0 / 255): every u8 value is exact in bf16 (8 significant bits).  Each fp32
+// weight is split into three bf16 parts w = hi + mid + lo (8 + 8 + 8 mantissa bits, exact), so
+// sum_k x_k * w_k = sum_k x_k*hi_k + x_k*mid_k + x_k*lo_k with every product exact in fp32 and fp32
+// accumulation inside v_mfma_f32_32x32x16_bf16 -- three matrix instructions at 16x the fp32-MFMA rate, i.e.
+// 5.3x fewer matrix cycles than the fp32-input instruction, and they leave the vector ALU free for the
+// u8 -> bf16 conversion.  K = 256 = 8 ky x 2 chunks of 16 (4 pixels x 4 frames = 16 contiguous bytes).
+// The split weights live in w1s[part][ky][kq][h][co][8] (bf16), refreshed whenever the parameters change.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void split_w1(const float w, int idx /* flat index in W_conv1[8][8][4][32] */, uint16_t *__restrict__ w1s) {
+    const int co = idx & 31, f = (idx >> 5) & 3, kx = (idx >> 7) & 7, ky = idx >> 10;
+    const int kq = kx >> 2, h = (kx >> 1) & 1, j = (kx & 1) * 4 + f;
+    const uint32_t hi = f32_to_bf16_rn(w);
+    const float r1 = w - __uint_as_float(hi << 16);
+    const uint32_t mid = f32_to_bf16_rn(r1);
+    const uint32_t lo = f32_to_bf16_rn(r1 - __uint_as_float(mid << 16));
+    const size_t o = ((((size_t)ky * 2 + kq) * 2 + h) * 32 + co) * 8 + j;
+    w1s[o] = (uint16_t)hi; w1s[8192 + o] = (uint16_t)mid; w1s[16384 + o] = (uint16_t)lo;
+}
+
+__global__ void w1_split_kernel(const float *__restrict__ params, uint16_t *__restrict__ w1s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 8192) split_w1(params[OFF_W1 + idx], idx, w1s);
+}
+
+__device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
+    uint4 o;
+    const float f0 = (float)(v.x & 255u), f1 = (float)((v.x >> 8) & 255u), f2 = (float)((v.x >> 16) & 255u), f3 = (float)(v.x >> 24);
+    const float f4 = (float)(v.y & 255u), f5 = (float)((v.y >> 8) & 255u), f6 = (float)((v.y >> 16) & 255u), f7 = (float)(v.y >> 24);
+    // upper halves of two floats -> one dword (exact: <= 8 significant bits)
+    o.x = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+    o.y = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+    o.z = __builtin_amdgcn_perm(__float_as_uint(f5), __float_as_uint(f4), 0x07060302u);
+    o.w = __builtin_amdgcn_perm(__float_as_uint(f7), __float_as_uint(f6), 0x07060302u);
+    return __builtin_bit_cast(bf16x8, o);
+}
+
+// conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2; one wave per tile of 8 pooled pixels x 4
+// window positions (the pool is a max over 4 accumulator registers of one lane), 48 bf16 MFMAs per tile.
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
+    const Slice s = sl.s[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int npool = s.count * 100, tile = blockIdx.x * 4 + wave;
+    if (tile * 8 >= npool) return;
+    const int P = tile * 8 + (i >> 2), pos = i & 3;
+    const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
+    const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+    const uint4 *WB = reinterpret_cast<const uint4 *>(s.w1s) + hl * 32 + j;      // [part][ky][kq][h][co] x 16 B
+    f32x16 acc = {0};
+#pragma unroll 2
+    for (int ky = 0; ky < 8; ky++) {
+        const int iy = oy * 4 + ky - 2;
+        const bool rowok = P < npool && iy >= 0 && iy < 80;
+        const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * 4;
+#pragma unroll
+        for (int kq = 0; kq < 2; kq++) {
+            const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;         // even: the pixel pair is inside or outside together
+            uint2 v = make_uint2(0u, 0u);
+            if (rowok && ix >= 0 && ix < 80) v = *reinterpret_cast<const uint2 *>(row + (size_t)ix * 4);
+            const bf16x8 A = u8x8_to_bf16(v);
+#pragma unroll
+            for (int part = 0; part < 3; part++) {
+                const uint4 wv = WB[((part * 8 + ky) * 2 + kq) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, wv), acc, 0, 0, 0);
+            }
+        }
+    }
+    const float bias = s.params[OFF_B1 + j];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        float bv = fmaxf(acc[4 * g] + bias, 0.f);
+        int best = 0;
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+            const float v = fmaxf(acc[4 * g + q] + bias, 0.f);
+            if (v > bv) { bv = v; best = q; }
+        }
+        const int Pp = tile * 8 + 2 * g + hl;
+        if (Pp < npool) {
+            const size_t o = ((size_t)s.s_off * 100 + Pp) * 32 + j;
+            p1[o] = bv; amax[o] = (uint8_t)best;
+        }
+    }
+}
+
+// ---- large-batch variants (the acting path: n = number of envs).  With thousands of output tiles there is no
+// need to split K over waves: every wave owns a whole 32x32 tile, runs the full K loop and writes its
+// result straight from the accumulator -- no LDS, no barrier, and two waves per SIMD hide the loads.
+// Operand fragments for a software pipeline: load_frag() issues the loads of the NEXT k-step while mma_frag()
+// consumes the CURRENT one (one wave per SIMD has nothing else to hide the L2 latency behind).
+template <int KH> struct Frag { float a[KH], b[KH]; };
+
+template <int KH>
+__device__ __forceinline__ void load_frag(Frag<KH> &f, const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
+                                          int bstride) {
+#pragma unroll
+    for (int q = 0; q < KH / 4; q++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        f.a[4 * q] = v.x; f.a[4 * q + 1] = v.y; f.a[4 * q + 2] = v.z; f.a[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < KH; t++) f.b[t] = bcol[(size_t)t * bstride];
+}
+
+template <int KH>
+__device__ __forceinline__ void mma_frag(const Frag<KH> &f, f32x16 &acc) {
+#pragma unroll
+    for (int t = 0; t < KH; t++) acc = mfma(f.a[t], f.b[t], acc);
+}
+
+__global__ __launch_bounds__(256) void conv2_big_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
+    const Slice s = sl.s[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int M = s.count * 25, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
+    auto issue = [&](int c, Frag<32> &f) {
+        const int ky = c >> 1, kx = 2 * (c & 1) + hl;
+        const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+        const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
+        const float *arun = p1 + (((size_t)(s.s_off + b) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
+        load_frag<32>(f, arun, ok, s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j, 64);
+    };
+    f32x16 acc = {0};
+    Frag<32> f0, f1;
+    issue(0, f0);
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        issue(c + 1, f1);
+        mma_frag<32>(f0, acc);
+        if (c + 2 < 8) issue(c + 2, f0);
+        mma_frag<32>(f1, acc);
+    }
+    const float bias = s.params[OFF_B2 + n0 + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int mr = tile * 32 + drow(r, lane);
+        if (mr < M) h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
+    const Slice s = sl.s[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int M = s.count * 25, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
+    auto issue = [&](int cell, Frag<32> &f) {
+        const int ky = cell / 3, kx = cell - ky * 3;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
+        const float *arun = h2 + ((size_t)(s.s_off + b) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
+        load_frag<32>(f, arun, ok, s.params + OFF_W3 + ((size_t)(cell * 64) + 32 * hl) * 64 + n0 + j, 64);
+    };
+    f32x16 acc = {0};
+    Frag<32> f0, f1;
+    issue(0, f0);
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        issue(c + 1, f1);
+        mma_frag<32>(f0, acc);
+        issue(c + 2, f0);
+        mma_frag<32>(f1, acc);
+    }
+    mma_frag<32>(f0, acc);
+    const float bias = s.params[OFF_B3 + n0 + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int mr = tile * 32 + drow(r, lane);
+        if (mr < M) h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
+    }
+}
+
 // fc1 1600xFC: the K = 1600 reduction is split over FC1_KS = 5 workgroups x 8 waves x 40 k, so every wave
 // issues its 40 operand loads at once and runs 20 MFMAs.  The 5 partial sums stay separate
 // (hfp[ks][sample][FC], no bias / relu yet): the two consumers (head_kernel, loss_head_kernel) add them in
@@ -217,6 +349,37 @@ __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__rest
             const int mr = tile * 32 + drow(r, lane);
             if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
         }
+    }
+}
+
+// large-batch fc1: one wave = one m-tile x one n-tile x one of the FC1_KS k-slices (320 k = 8 steps of 20 k per
+// lane half), software pipelined, no LDS
+__global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
+                                                      int stot) {
+    const int z = blockIdx.z / FC1_KS, ks = blockIdx.z - z * FC1_KS;
+    const Slice s = sl.s[z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
+    const int M = s.count, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
+    if (tile * 32 >= M) return;
+    const int m = tile * 32 + i;
+    const bool ok = m < M;
+    const int k0 = ks * 320 + hl * 160;
+    const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
+    const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
+    f32x16 acc = {0};
+    Frag<20> f0, f1;
+    load_frag<20>(f0, arun, ok, bcol, FC);
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        load_frag<20>(f1, arun + 20 * (c + 1), ok, bcol + (size_t)20 * (c + 1) * FC, FC);
+        mma_frag<20>(f0, acc);
+        if (c + 2 < 8) load_frag<20>(f0, arun + 20 * (c + 2), ok, bcol + (size_t)20 * (c + 2) * FC, FC);
+        mma_frag<20>(f1, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int mr = tile * 32 + drow(r, lane);
+        if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
     }
 }
 
@@ -530,29 +693,35 @@ __global__ __launch_bounds__(576) void conv3_dx_kernel(const float *__restrict__
     }
 }
 
-// conv2 data gradient -> dp1 (masked by relu1 through the pool: p1 > 0); 8 waves x 2 cells
-__global__ __launch_bounds__(512) void conv2_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh2,
+// conv2 data gradient -> dp1 (masked by relu1 through the pool: p1 > 0).  Stride 2 means an input pixel
+// (iy, ix) only meets the 4 kernel cells with ky = iy + 1 and kx = ix + 1 (mod 2): tiles are built per parity
+// class (blockIdx.y) from the 25 pixels of that class per sample, and the 4 waves take the 4 live cells --
+// a quarter of the MFMAs a class-blind tiling would issue.
+__global__ __launch_bounds__(256) void conv2_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh2,
                                                        const float *__restrict__ p1, float *__restrict__ dp1, int B) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[3 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = B * 100, tile = blockIdx.x;
-    const int m = tile * 32 + i, b = m / 100, rem = m - b * 100, iy = rem / 10, ix = rem - iy * 10;
+    const int M = B * 25, tile = blockIdx.x, py = blockIdx.y >> 1, px = blockIdx.y & 1;
+    const int ky = ((py + 1) & 1) + 2 * (wave >> 1), kx = ((px + 1) & 1) + 2 * (wave & 1);
+    const int m = tile * 32 + i, b = m / 25, q = m - b * 25, qy = q / 5, qx = q - qy * 5;
+    const int iy = py + 2 * qy, ix = px + 2 * qx;
+    const int ty = iy + 1 - ky, tx = ix + 1 - kx;                 // even by construction
+    const bool ok = m < M && ty >= 0 && tx >= 0 && (ty >> 1) < 5 && (tx >> 1) < 5;
+    const int cell = ky * 4 + kx;
+    const float *arun = dh2 + ((size_t)b * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
+    const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
     f32x16 acc = {0};
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int cell = wave * 2 + c, ky = cell >> 2, kx = cell & 3;
-        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
-        const bool ok = m < M && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < 5 && (tx >> 1) < 5;
-        const float *arun = dh2 + ((size_t)b * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
-        const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
-        mma_run_run<32>(arun, ok, brun, acc);
-    }
-    reduce_waves<8>(acc, red, wave, lane);
+    mma_run_run<32>(arun, ok, brun, acc);
+    reduce_waves<4>(acc, red, wave, lane);
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) { const size_t o = (size_t)mr * 32 + j; dp1[o] = p1[o] > 0.f ? acc[r] : 0.f; }
+            if (mr < M) {
+                const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
+                const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
+                dp1[o] = p1[o] > 0.f ? acc[r] : 0.f;
+            }
         }
     }
 }
@@ -564,18 +733,31 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_
     if (idx >= CONV_PARAMS) return;
     const int z = idx < OFF_W2 ? z1 : (idx < OFF_W3 ? z2 : z3);
     float s = 0.f;
+#pragma unroll 8
     for (int q = 0; q < z; q++) s += slabs[q * slab_stride + idx];
     grad[idx] = s;
 }
 
-// TF ApplyAdam, fp32, float4 wide
+// TF ApplyAdam, fp32, float4 wide.  When `slabs` is given the conv gradients are still spread over the
+// reduction slabs of conv_dw_kernel: they are summed here, in slab order, instead of in a separate launch.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
-                                                   const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad) {
+                                                   const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad,
+                                                   const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
+                                                   uint16_t *__restrict__ w1s) {
     const float alpha = ad->alpha, omb1 = 1.f - ad->b1, omb2 = 1.f - ad->b2, eps = ad->eps;
     const long long n4 = n >> 2;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4 *>(p)[q], Mv = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
-        const float4 Gv = reinterpret_cast<const float4 *>(g)[q];
+        float4 Gv;
+        if (slabs && q * 4 < CONV_PARAMS) {                      // region boundaries are multiples of 4
+            const int idx = (int)q * 4, z = idx < OFF_W2 ? z1 : (idx < OFF_W3 ? z2 : z3);
+            Gv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int s = 0; s < z; s++) {
+                const float4 t = *reinterpret_cast<const float4 *>(slabs + s * slab_stride + idx);
+                Gv.x += t.x; Gv.y += t.y; Gv.z += t.z; Gv.w += t.w;
+            }
+        } else Gv = reinterpret_cast<const float4 *>(g)[q];
 #define FB_ADAM1(c)                                  \
         Mv.c += (Gv.c - Mv.c) * omb1;                \
         V.c += (Gv.c * Gv.c - V.c) * omb2;           \
@@ -583,6 +765,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
         FB_ADAM1(x) FB_ADAM1(y) FB_ADAM1(z) FB_ADAM1(w)
 #undef FB_ADAM1
         reinterpret_cast<float4 *>(p)[q] = P; reinterpret_cast<float4 *>(m)[q] = Mv; reinterpret_cast<float4 *>(v)[q] = V;
+        if (q * 4 < OFF_B1) {                                    // W_conv1 changed: refresh its bf16 hi/mid/lo split
+            const int idx = (int)q * 4;
+            split_w1(P.x, idx, w1s); split_w1(P.y, idx + 1, w1s); split_w1(P.z, idx + 2, w1s); split_w1(P.w, idx + 3, w1s);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long q = (n4 << 2) + threadIdx.x;
@@ -617,12 +803,16 @@ struct fb_qnet {
     long long n;
     NetOff off;
     float *params[2], *adam_m, *adam_v, *grad, *slabs;
+    uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
     int zmax;
+    hipStream_t side;                // weight-gradient kernels run here, beside the data-gradient chain
+    hipEvent_t ev[4];
+    int overlap;
 };
 
 static NetOff make_off(int FC, int A, int dueling) {
@@ -645,7 +835,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     h->arch = arch; h->FC = fc_width; h->A = n_actions; h->max_batch = max_batch;
     h->off = make_off(fc_width, n_actions, arch == FB_ARCH_DUELING);
     h->n = h->off.n;
-    h->zmax = 32;
+    h->zmax = 64;
     const size_t S = (size_t)3 * max_batch, nb = sizeof(float) * (size_t)h->n;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); };
@@ -653,6 +843,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->adam_m, nb); alloc((void **)&h->adam_v, nb); alloc((void **)&h->grad, nb);
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
+    alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
     alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
@@ -664,15 +855,22 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
         fb_qnet_destroy(h);
         return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { fb_set_error(FB_ERR_HIP, "fb_qnet_create: %s", hipGetErrorString(e)); fb_qnet_destroy(h); return FB_ERR_HIP; }
+    const char *ov = getenv("FB_QNET_OVERLAP");
+    h->overlap = ov ? atoi(ov) : 0;      // measured slower than the plain chain on MI355X (events cost more than they hide)
     *out = h;
     return fb_qnet_set_hparams(h, 1e-6f, 0.9f, 0.999f, 1e-8f);
 }
 
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
-    void *ptrs[] = {h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+    void *ptrs[] = {h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return FB_OK;
 }
@@ -700,6 +898,7 @@ extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *
     hipLaunchKernelGGL(init_params_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, fb_stream(stream),
                        h->params[which], h->n, h->off, h->FC, h->A, h->arch == FB_ARCH_DUELING, (uint32_t)seed,
                        (uint32_t)(seed >> 32));
+    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -707,6 +906,8 @@ extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *
 extern "C" int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat, void *stream) {
     FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_load_params: bad argument");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[which], flat, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
+    FB_LAUNCH_CHECK();
     return FB_OK;
 }
 
@@ -766,11 +967,23 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
 #define FB_K(id) if (only < 0 || only == (id))
     int maxc = 0, total = 0;
     for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
-    FB_K(K_CONV1) hipLaunchKernelGGL(conv1_pool_kernel, dim3((maxc * 100 + 7) / 8, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
-    FB_K(K_CONV2) hipLaunchKernelGGL(conv2_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
-    FB_K(K_CONV3) hipLaunchKernelGGL(conv3_kernel, dim3((maxc * 25 + 31) / 32, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
+    // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
+    const bool big = maxc >= 256;
+    const int t1 = (maxc * 100 + 7) / 8, t23 = (maxc * 25 + 31) / 32;
+    FB_K(K_CONV1) hipLaunchKernelGGL(conv1_pool_kernel, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+    FB_K(K_CONV2) {
+        if (big) hipLaunchKernelGGL(conv2_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->p1, h->h2);
+        else hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
+    }
+    FB_K(K_CONV3) {
+        if (big) hipLaunchKernelGGL(conv3_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->h2, h->h3);
+        else hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
+    }
     const int stot = 3 * h->max_batch;
-    FB_K(K_FC1) hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
+    FB_K(K_FC1) {
+        if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
+        else hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
+    }
     FB_K(K_HEAD) {
         HeadArgs H;
         H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.q = h->q; H.FC = h->FC; H.A = h->A;
@@ -790,7 +1003,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.adam = h->adam; L.tick = p.tick;
             hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
         }
-        FB_K(K_FC1_DW) hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, st, h->h3, h->dhf, G, B, FC);
+        // The weight-gradient kernels only feed Adam, the data-gradient kernels feed each other: fork the dW
+        // launches onto a side stream (events = graph edges when captured) and join before the update.
+        const bool fork = only < 0 && h->overlap;
+        hipStream_t sw = fork ? h->side : st;
+        if (fork) { (void)hipEventRecord(h->ev[0], st); (void)hipStreamWaitEvent(sw, h->ev[0], 0); }
+        FB_K(K_FC1_DW) hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, sw, h->h3, h->dhf, G, B, FC);
         FB_K(K_FC1_DX) hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(512), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
         // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
         int z3 = (B * 25 + 255) / 256, z1 = (B * 400 + 255) / 256;
@@ -798,17 +1016,23 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (z1 > h->zmax) z1 = h->zmax;
         const int z2 = z3;
         const size_t ss = CONV_PARAMS;
-        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<3>, dim3(36 + 2, z3), dim3(512), 0, st, B, h->h2, (const uint8_t *)nullptr,
+        if (fork) { (void)hipEventRecord(h->ev[1], st); (void)hipStreamWaitEvent(sw, h->ev[1], 0); }
+        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<3>, dim3(36 + 2, z3), dim3(512), 0, sw, B, h->h2, (const uint8_t *)nullptr,
                                             h->dh3, (const uint8_t *)nullptr, h->slabs, ss);
         FB_K(K_CONV3_DX) hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
-        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<2>, dim3(32 + 2, z2), dim3(512), 0, st, B, h->p1, (const uint8_t *)nullptr,
+        if (fork) { (void)hipEventRecord(h->ev[2], st); (void)hipStreamWaitEvent(sw, h->ev[2], 0); }
+        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<2>, dim3(32 + 2, z2), dim3(512), 0, sw, B, h->p1, (const uint8_t *)nullptr,
                                             h->dh2, (const uint8_t *)nullptr, h->slabs, ss);
-        FB_K(K_CONV2_DX) hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 100 + 31) / 32), dim3(512), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
+        if (fork) (void)hipEventRecord(h->ev[3], sw);
+        FB_K(K_CONV2_DX) hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 25 + 31) / 32, 4), dim3(256), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
         FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv_dw_kernel<1>, dim3(8 + 1, z1), dim3(512), 0, st, B, (const float *)nullptr, p.s, h->dp1,
                                             h->amax, h->slabs, ss);
-        FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
+        if (fork) (void)hipStreamWaitEvent(st, h->ev[3], 0);
+        // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
+        if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
-            hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam);
+            hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam,
+                               (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0]);
     }
 #undef FB_K
     FB_LAUNCH_CHECK();
@@ -817,7 +1041,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
 
 static Plan forward_plan(fb_qnet *h, int which, const uint8_t *states, int n) {
     Plan p; memset(&p, 0, sizeof(p));
-    p.sl.s[0] = Slice{h->params[which], states, 0, n};
+    p.sl.s[0] = Slice{h->params[which], states, 0, n, h->w1s[which]};
     p.ns = 1;
     return p;
 }
@@ -847,7 +1071,8 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     FB_REQUIRE(h && flat_grad, "fb_qnet_apply_adam: NULL argument");
     hipStream_t st = fb_stream(stream);
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
-    hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam);
+    hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
+                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0]);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -855,6 +1080,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
 extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     FB_REQUIRE(h, "fb_qnet_sync_target: NULL handle");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[1], h->params[0], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    FB_CHECK_HIP(hipMemcpyAsync(h->w1s[1], h->w1s[0], 3 * 8192 * 2, hipMemcpyDeviceToDevice, fb_stream(stream)));
     return FB_OK;
 }
 
@@ -868,10 +1094,10 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
     Plan p; memset(&p, 0, sizeof(p));
     // forward: s through the online net, s' through the net(s) the algorithm asks for
     p.ns = 2;
-    p.sl.s[0] = Slice{h->params[0], s, 0, B};
-    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B};               // BrainDQN.py:205 (same net)
-    else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B}; p.ns = 3; }
-    else p.sl.s[1] = Slice{h->params[1], s2, B, B};                                   // target net
+    p.sl.s[0] = Slice{h->params[0], s, 0, B, h->w1s[0]};
+    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]};               // BrainDQN.py:205 (same net)
+    else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B, h->w1s[1]}; p.ns = 3; }
+    else p.sl.s[1] = Slice{h->params[1], s2, B, B, h->w1s[1]};                                   // target net
     p.train = true; p.algo = algo; p.B = B; p.s = s; p.a = a; p.r = r; p.t = t; p.isw = isw; p.gamma = gamma;
     p.loss = loss; p.abs_err = abs_err; p.y = q_target;
     p.G = flat_grad ? flat_grad : h->grad;

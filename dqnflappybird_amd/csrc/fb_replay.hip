@@ -182,8 +182,12 @@ __device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
     }
 }
 
-// random.sample(range(n), k) on one wave; every lane runs the same control flow, lane (i & 63)
-// keeps result i in register slot i >> 6.
+// random.sample(range(n), k) on one wave.  Set path (n > setsize, the normal case): the wave tempers up to
+// 64 state words at once, ballots the ones below n and walks only those, in stream order, testing each
+// against the already selected values with one wave-wide compare -- no per-word LDS round trip.  Words are
+// consumed exactly like CPython consumes them (every getrandbits call, also rejected / duplicate ones, up
+// to and including the word that completed the sample).  Pool path (n <= setsize): the modulus shrinks
+// with every draw, so it stays word-serial.  Lane (i & 63) keeps result i in register slot i >> 6.
 __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
                                                             long long *__restrict__ out) {
     __shared__ uint32_t mt[624];
@@ -200,31 +204,45 @@ __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int 
     }
     __syncthreads();
     long long sel[4] = {-1, -1, -1, -1};
-    const bool use_pool = n <= setsize;
-    if (use_pool) { for (int i = lane; i < (int)n; i += 64) pool[i] = i; }
-    __syncthreads();
-    for (int i = 0; i < k; i++) {
-        const uint32_t m = use_pool ? (uint32_t)(n - i) : (uint32_t)n;
-        const int nbits = 32 - __builtin_clz(m);
-        uint32_t r;
-        for (;;) {                                      // _randbelow_with_getrandbits (+ the `in selected` retry)
+    if (n > setsize) {
+        const int shift = __builtin_clz((uint32_t)n);   // 32 - n.bit_length()
+        int i = 0;
+        while (i < k) {
             if (idx >= 624) { mt_regen(mt, lane); idx = 0; }
-            r = mt_temper(mt[idx++]) >> (32 - nbits);
-            if (r >= m) continue;
-            if (use_pool) break;
-            bool dup = false;
+            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
+            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
+            unsigned long long mask = __ballot(lane < take && w < (uint32_t)n);
+            int consumed = take;
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const long long c = (long long)__shfl(w, l);
+                bool dup = false;
 #pragma unroll
-            for (int q = 0; q < 4; q++) dup |= (sel[q] == (long long)r);
-            if (!__any(dup)) break;
+                for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
+                if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
+                if (lane == (i & 63)) sel[i >> 6] = c;
+                if (++i == k) { consumed = l + 1; break; }
+            }
+            idx += consumed;
         }
-        long long res = r;
-        if (use_pool) {
-            res = pool[r];
+    } else {
+        for (int i = lane; i < (int)n; i += 64) pool[i] = i;
+        __syncthreads();
+        for (int i = 0; i < k; i++) {
+            const uint32_t m = (uint32_t)(n - i);
+            const int nbits = 32 - __builtin_clz(m);
+            uint32_t r;
+            do {                                        // _randbelow_with_getrandbits
+                if (idx >= 624) { mt_regen(mt, lane); idx = 0; }
+                r = mt_temper(mt[idx++]) >> (32 - nbits);
+            } while (r >= m);
+            const long long res = pool[r];
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) pool[r] = pool[m - 1];
             __builtin_amdgcn_wave_barrier();
+            if (lane == (i & 63)) sel[i >> 6] = res;
         }
-        if (lane == (i & 63)) sel[i >> 6] = res;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];

@@ -29,6 +29,13 @@
 #include <string.h>
 #include "fbo.h"
 
+/* Smallest distance of any ReLU input from 0 / of any pool winner from its runner-up seen by the last
+ * fbo_qnet_forward: gradient checks through ReLUs are only meaningful away from the kinks, the tests use
+ * this to pick data with a safe margin. */
+static __thread float g_margin = 1e30f;
+float fbo_qnet_last_margin(void) { return g_margin; }
+static inline void margin(float v) { float a = v < 0 ? -v : v; if (a < g_margin) g_margin = a; }
+
 enum { O_W1 = 0, O_B1 = 8192, O_W2 = 8224, O_B2 = 40992, O_W3 = 41056, O_B3 = 77920, O_WF1 = 77984 };
 
 typedef struct { size_t wf1, bf1, wq, bq, wv, bv, n; } offs_t;
@@ -73,6 +80,7 @@ static void conv(const float *in, int H, int W, int Ci, const float *wt, const f
             }
             for (int co = 0; co < Co; co++) {
                 float v = (float)acc[co] + bias[co];       /* conv output is a float tensor, then + b */
+                margin(v);
                 out[((size_t)oy * Wo + ox) * Co + co] = v > 0 ? v : 0;
             }
         }
@@ -107,6 +115,7 @@ void fbo_qnet_forward(const float *P, fbo_qcfg c, const uint8_t *states, int B, 
     size_t AF = fbo_qnet_act_floats(c);
     float *x = (float *)malloc(sizeof(float) * 25600);
     float *tmp = acts ? NULL : (float *)malloc(sizeof(float) * AF);
+    g_margin = 1e30f;
     for (int b = 0; b < B; b++) {
         float *a = acts ? acts + (size_t)b * AF : tmp;
         const uint8_t *s = states + (size_t)b * 25600;
@@ -115,12 +124,13 @@ void fbo_qnet_forward(const float *P, fbo_qcfg c, const uint8_t *states, int B, 
         for (int py = 0; py < 10; py++)                        /* max_pool 2x2 s2, BrainDQN.py:128 */
             for (int px = 0; px < 10; px++)
                 for (int ch = 0; ch < 32; ch++) {
-                    float m = -INFINITY;
+                    float m = -INFINITY, m2 = -INFINITY;
                     for (int dy = 0; dy < 2; dy++)
                         for (int dx = 0; dx < 2; dx++) {
                             float v = a[A_H1 + ((2 * py + dy) * 20 + 2 * px + dx) * 32 + ch];
-                            if (v > m) m = v;
+                            if (v > m) { m2 = m; m = v; } else if (v > m2) m2 = v;
                         }
+                    if (m > 0) margin(m - m2);             /* how clearly the pool winner wins */
                     a[A_P1 + (py * 10 + px) * 32 + ch] = m;
                 }
         conv(a + A_P1, 10, 10, 32, P + O_W2, P + O_B2, 4, 2, 1, 5, 5, 64, a + A_H2);
@@ -129,6 +139,7 @@ void fbo_qnet_forward(const float *P, fbo_qcfg c, const uint8_t *states, int B, 
             double acc = 0;
             for (int i = 0; i < 1600; i++) acc += (double)a[A_H3 + i] * (double)P[o.wf1 + (size_t)i * c.fc + j];
             float v = (float)acc + P[o.bf1 + j];
+            margin(v);
             a[A_HF + j] = v > 0 ? v : 0;
         }
         head(P, c, o, a + A_HF, q + (size_t)b * c.actions);

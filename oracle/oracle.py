@@ -79,6 +79,7 @@ def lib():
         L.fbo_qnet_act_floats.argtypes = [QCfg]
         L.fbo_qnet_forward.argtypes = [C.c_void_p, QCfg, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.fbo_qnet_backward.argtypes = [C.c_void_p, QCfg, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbo_qnet_last_margin.restype = C.c_float
         L.fbo_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_void_p] * 2
         L.fbo_dqn_loss.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 4
         L.fbo_trunc_normal_init.argtypes = [C.c_void_p, QCfg, C.c_uint32, C.c_uint32]
@@ -291,6 +292,11 @@ def dqn_loss(kind, q, q_next_sel, action, reward, terminal, isw=None, gamma=0.99
     lib().fbo_dqn_loss(kind, B, A, _p(q), _p(qn), _p(action), _p(reward), _p(terminal), _p(isw), gamma,
                        _p(y), C.byref(loss), _p(ae), _p(dq))
     return y, loss.value, ae, dq
+
+
+def last_margin():
+    """Smallest |ReLU input| and pool win margin seen by the last forward() call."""
+    return lib().fbo_qnet_last_margin()
 
 
 class Adam:

@@ -68,18 +68,24 @@ def oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw):
 def test_train_step_gradients_match_oracle(torch_cuda, oracle, algo, dueling, B):
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet
-    # fixed data per case (zlib.crc32, not the per-process str hash).  A gradient check through ReLUs is
-    # only meaningful away from the kinks: with other data one of the 51 200 conv activations per layer
-    # can sit within 1e-7 of zero, the fp32 device and the fp64-accumulating oracle then disagree on
-    # its mask and that unit's whole gradient column differs (seen once: conv2 channel 18, PYTHONHASHSEED=2).
+    # A gradient check through ReLUs / max-pools is only meaningful away from their kinks: if one of the
+    # ~100 000 unit inputs per layer sits within rounding distance of 0 (or a pool winner within rounding
+    # distance of its runner-up), the fp32 device and the fp64-accumulating oracle disagree on that unit's
+    # mask and its whole gradient column differs.  Draw data until the oracle reports a safe margin.
     import zlib
-    rng = np.random.default_rng(zlib.crc32(f"{algo}-{dueling}-{B}".encode()))
     cfg = oracle.qcfg(512, 2, dueling)
     p_on, p_tg = trained_like_params(oracle, cfg, 1), trained_like_params(oracle, cfg, 2)
     net = QNet(2, 512, "dueling" if dueling else "plain", max_batch=64)
     net.load_params(p_on, 0)
     net.load_params(p_tg, 1)
-    s, s2 = rand_states(rng, B), rand_states(rng, B)
+    for attempt in range(50):
+        rng = np.random.default_rng(zlib.crc32(f"{algo}-{dueling}-{B}-{attempt}".encode()))
+        s, s2 = rand_states(rng, B), rand_states(rng, B)
+        oracle.forward(p_on, cfg, s)
+        if oracle.last_margin() > 2e-5:          # device vs oracle pre-activations differ by ~1e-6
+            break
+    else:
+        pytest.fail("no kink-free batch found")
     a = rng.integers(0, 2, B).astype(np.uint8)
     r = rng.choice(np.array([0.1, 3, -3], np.float32), B, p=[0.8, 0.1, 0.1])
     t = (r == -3).astype(np.uint8)
@@ -117,7 +123,11 @@ def test_adam_updates_match_oracle_over_10_steps(torch_cuda, oracle):
     p_ref = p.copy()
     for step in range(10):
         B = 32
-        s, s2 = rand_states(rng, B), rand_states(rng, B)
+        for _ in range(50):                       # stay away from ReLU / pool kinks (see the gradient test)
+            s, s2 = rand_states(rng, B), rand_states(rng, B)
+            oracle.forward(p_ref, cfg, s)
+            if oracle.last_margin() > 2e-5:
+                break
         a = rng.integers(0, 2, B).astype(np.uint8)
         r = rng.choice(np.array([0.1, 3, -3], np.float32), B)
         t = (r == -3).astype(np.uint8)
