@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
                                                   int32_t *__restrict__ score) {
     __shared__ EnvLds L;
+    __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
@@ -188,32 +189,82 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
                 if (bad) atomicAdd(p.err_count, 1ull);
             }
         }
-        // ---- observation: 100 ballot words of 64 pixels, p = r*80 + c
+        // ---- observation, one wave per output row r (lane = column c < 63; columns >= 63 come from the ground
+        // table).  Everything that depends on the row only -- which sprite column each of the two x taps falls
+        // in -- is computed once per row in scalar registers; rows whose taps touch neither the bird nor a pipe
+        // are all background and skip the per-pixel work.  The 80 bits of a row are OR-ed into the frame's 100
+        // packed words in LDS (a row straddles two or three words), then written out coalesced.
         const int gidx = (-st[4]) >> 2;                           // basex in {0,-4,..,-44}
-        for (int w = wave; w < 100; w += 4) {
-            const int pix = w * 64 + lane;
-            const int r = pix / OBS, c = pix - r * OBS;
-            int bit;
-            if (c >= GROUND_C0) {
-                bit = (L.ground_bits[gidx * OBS + r] >> (c - GROUND_C0)) & 1;
-            } else {
-                const int x0 = L.xo[r], y0 = L.yo[c];
-                int i00 = bird_at(L, st, x0, y0), i01 = bird_at(L, st, x0, y0 + 1);
-                int i10 = bird_at(L, st, x0 + 1, y0), i11 = bird_at(L, st, x0 + 1, y0 + 1);
-                if (!i00) i00 = pipe_at(L, st, x0, y0);
-                if (!i01) i01 = pipe_at(L, st, x0, y0 + 1);
-                if (!i10) i10 = pipe_at(L, st, x0 + 1, y0);
-                if (!i11) i11 = pipe_at(L, st, x0 + 1, y0 + 1);
-                bit = 0;
-                if (i00 | i01 | i10 | i11)
-                    bit = resize_gray_bit(L.pal[i00], L.pal[i01], L.pal[i10], L.pal[i11], L.ya0[c], L.ya1[c],
-                                          L.xb0[r], L.xb1[r]);
+        for (int w = threadIdx.x; w < 100; w += 256) fw[w] = 0ull;
+        __syncthreads();
+        const int py = __builtin_amdgcn_readfirstlane(st[0]), pidx = __builtin_amdgcn_readfirstlane(st[2]);
+        const int npipes = __builtin_amdgcn_readfirstlane(st[6]);
+        int pxs[3], gys[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { pxs[i] = __builtin_amdgcn_readfirstlane(st[7 + i]); gys[i] = gap_y(__builtin_amdgcn_readfirstlane(st[10 + i])); }
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int r = wv; r < OBS; r += 4) {
+            const int x0 = L.xo[r];
+            int bcol[2], pcol[2], pgy[2];                         // per x tap: bird column / pipe column (or -1) and its gap
+            bool any = false;
+#pragma unroll
+            for (int tx = 0; tx < 2; tx++) {
+                const int x = x0 + tx;
+                bcol[tx] = (x >= PLAYERX && x < PLAYERX + BIRD_W) ? x - PLAYERX : -1;
+                pcol[tx] = -1; pgy[tx] = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int col = x - pxs[i];
+                    if (i < npipes && col >= 0 && col < PIPE_W) { pcol[tx] = col; pgy[tx] = gys[i]; }
+                }
+                any |= bcol[tx] >= 0 || pcol[tx] >= 0;
             }
-            const unsigned long long m = __ballot(bit);
-            if (frame_bits && lane == 0) frame_bits[(size_t)env * 100 + w] = m;
-            if (frames) frames[(size_t)env * 6400 + pix] = bit ? 255 : 0;
+            unsigned long long m = 0ull;
+            if (any) {
+                const int c = lane < GROUND_C0 ? lane : 0;
+                const int y0 = L.yo[c];
+                int idx[2][2];
+#pragma unroll
+                for (int tx = 0; tx < 2; tx++)
+#pragma unroll
+                    for (int ty = 0; ty < 2; ty++) {
+                        const int y = y0 + ty, by = y - py;
+                        int v = 0;
+                        if (bcol[tx] >= 0 && by >= 0 && by < BIRD_H) v = L.bird[(pidx * BIRD_H + by) * BIRD_W + bcol[tx]];
+                        if (!v && pcol[tx] >= 0) {
+                            if (y < pgy[tx]) v = L.pipe[(pgy[tx] - 1 - y) * PIPE_W + (PIPE_W - 1 - pcol[tx])];
+                            else if (y >= pgy[tx] + GAP) v = L.pipe[(y - pgy[tx] - GAP) * PIPE_W + pcol[tx]];
+                        }
+                        idx[tx][ty] = v;
+                    }
+                int bit = 0;
+                if (idx[0][0] | idx[0][1] | idx[1][0] | idx[1][1])
+                    bit = resize_gray_bit(L.pal[idx[0][0]], L.pal[idx[0][1]], L.pal[idx[1][0]], L.pal[idx[1][1]], L.ya0[c],
+                                          L.ya1[c], L.xb0[r], L.xb1[r]);
+                m = __ballot(bit && lane < GROUND_C0);
+            }
+            if (lane == 0) {
+                const unsigned long long g = L.ground_bits[gidx * OBS + r];       // 17 bits, columns 63..79
+                const int p0 = r * OBS, w0 = p0 >> 6, sh = p0 & 63;               // row = bits [p0, p0 + 80)
+                const unsigned long long lo = m | (g << GROUND_C0);               // columns 0..63 (bit 63 = column 63)
+                const unsigned long long hi = g >> 1;                             // columns 64..79
+                atomicOr(&fw[w0], lo << sh);
+                if (sh) atomicOr(&fw[w0 + 1], (lo >> (64 - sh)) | (hi << sh));
+                else atomicOr(&fw[w0 + 1], hi);
+                if (sh > 48) atomicOr(&fw[w0 + 2], hi >> (64 - sh));
+            }
         }
-        __syncthreads();                                          // keep the waves of this workgroup on the same env
+        __syncthreads();
+        if (frame_bits) for (int w = threadIdx.x; w < 100; w += 256) frame_bits[(size_t)env * 100 + w] = fw[w];
+        if (frames) {
+            for (int q = threadIdx.x; q < 1600; q += 256) {                       // 4 pixels -> one 32-bit store
+                const unsigned int nib = (unsigned int)(fw[q >> 4] >> ((q & 15) * 4)) & 0xFu;
+                const unsigned int v = ((nib & 1u) * 0xFFu) | (((nib >> 1) & 1u) * 0xFF00u) | (((nib >> 2) & 1u) * 0xFF0000u) |
+                                       (((nib >> 3) & 1u) * 0xFF000000u);
+                reinterpret_cast<unsigned int *>(frames + (size_t)env * 6400)[q] = v;
+            }
+        }
+        __syncthreads();                                          // fw is reused by the next env of this workgroup
     }
 }
 

@@ -352,28 +352,30 @@ __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__rest
     }
 }
 
-// large-batch fc1: one wave = one m-tile x one n-tile x one of the FC1_KS k-slices (320 k = 8 steps of 20 k per
-// lane half), software pipelined, no LDS
+// large-batch fc1: one wave = one m-tile x one n-tile x one of FC1_BIG_KS = 2 k-slices (800 k = 20 steps of 20 k
+// per lane half; with 1024 samples that is exactly one wave per SIMD), software pipelined, no LDS
+constexpr int FC1_BIG_KS = 2;
+
 __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
                                                       int stot) {
-    const int z = blockIdx.z / FC1_KS, ks = blockIdx.z - z * FC1_KS;
+    const int z = blockIdx.z / FC1_BIG_KS, ks = blockIdx.z - z * FC1_BIG_KS;
     const Slice s = sl.s[z];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int M = s.count, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
     if (tile * 32 >= M) return;
     const int m = tile * 32 + i;
     const bool ok = m < M;
-    const int k0 = ks * 320 + hl * 160;
+    const int k0 = ks * 800 + hl * 400;
     const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
     const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
     f32x16 acc = {0};
     Frag<20> f0, f1;
     load_frag<20>(f0, arun, ok, bcol, FC);
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
+#pragma unroll 2
+    for (int c = 0; c < 20; c += 2) {
         load_frag<20>(f1, arun + 20 * (c + 1), ok, bcol + (size_t)20 * (c + 1) * FC, FC);
         mma_frag<20>(f0, acc);
-        if (c + 2 < 8) load_frag<20>(f0, arun + 20 * (c + 2), ok, bcol + (size_t)20 * (c + 2) * FC, FC);
+        if (c + 2 < 20) load_frag<20>(f0, arun + 20 * (c + 2), ok, bcol + (size_t)20 * (c + 2) * FC, FC);
         mma_frag<20>(f1, acc);
     }
 #pragma unroll
@@ -384,16 +386,15 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
 }
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
-__device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot, int FC, int smp, int jj, float bias) {
+__device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot, int FC, int smp, int jj, float bias, int nks) {
     float v = hfp[(size_t)smp * FC + jj];
-#pragma unroll
-    for (int ks = 1; ks < FC1_KS; ks++) v += hfp[((size_t)ks * stot + smp) * FC + jj];
+    for (int ks = 1; ks < nks; ks++) v += hfp[((size_t)ks * stot + smp) * FC + jj];
     return fmaxf(v + bias, 0.f);
 }
 
 // fc2 / dueling head (+ epsilon-greedy action for the acting path); one wave per sample
 struct HeadArgs {
-    Slices sl; int nslices; const float *hf; int stot; float *q; int FC, A, dueling; NetOff off;
+    Slices sl; int nslices; const float *hf; int stot, nks; float *q; int FC, A, dueling; NetOff off;
     uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
 };
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
 #pragma unroll
     for (int a = 0; a <= MAXA; a++) acc[a] = 0.f;
     for (int jj = lane; jj < H.FC; jj += 64) {
-        const float x = fc1_out(H.hf, H.stot, H.FC, smp, jj, P[H.off.bf1 + jj]);
+        const float x = fc1_out(H.hf, H.stot, H.FC, smp, jj, P[H.off.bf1 + jj], H.nks);
 #pragma unroll
         for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x, P[H.off.wq + jj * H.A + a], acc[a]);
         if (H.dueling) acc[MAXA] = fmaf(x, P[H.off.wv + jj], acc[MAXA]);
@@ -452,7 +453,7 @@ struct LossArgs {
     NetOff off;
     const float *params;            // online
     const float *q;                 // [3B][A] workspace
-    const float *hf; int stot;      // fc1 partials [FC1_KS][stot][FC]; rows 0..B-1 = s through the online net
+    const float *hf; int stot, nks; // fc1 partials [nks][stot][FC]; rows 0..B-1 = s through the online net
     const uint8_t *act; const float *rew; const uint8_t *term; const float *isw;
     double gamma;
     float *grad, *dhf, *loss, *abs_err, *y_out;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     for (int a = 0; a < MAXA; a++) { gw[a] = 0.f; wrow[a] = a < A ? P[L.off.wq + jj * A + a] : 0.f; }
     const float wvj = L.dueling ? P[L.off.wv + jj] : 0.f, bias = P[L.off.bf1 + jj];
     for (int b = bg; b < B; b += 4) {
-        const float h = fc1_out(L.hf, L.stot, L.FC, b, jj, bias);
+        const float h = fc1_out(L.hf, L.stot, L.FC, b, jj, bias, L.nks);
         float d = dv[b] * wvj;
 #pragma unroll
         for (int a = 0; a < MAXA; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
@@ -981,12 +982,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     const int stot = 3 * h->max_batch;
     FB_K(K_FC1) {
-        if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
+        if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_BIG_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
         else hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
     }
     FB_K(K_HEAD) {
         HeadArgs H;
-        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.q = h->q; H.FC = h->FC; H.A = h->A;
+        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
         H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
         H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
         H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
@@ -998,7 +999,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         FB_K(K_LOSS) {
             LossArgs L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
-            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
+            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = big ? FC1_BIG_KS : FC1_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
             L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             L.adam = h->adam; L.tick = p.tick;
             hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);

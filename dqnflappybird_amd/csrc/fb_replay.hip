@@ -74,12 +74,14 @@ __global__ __launch_bounds__(64) void reset_kernel(ReplayParams P, const uint8_t
     }
 }
 
-__global__ __launch_bounds__(64) void push_kernel(ReplayParams P, const uint8_t *__restrict__ frames,
+// `steps` (the index of the transition this push writes) is passed by value: the host handle counts pushes,
+// so no workgroup has to read the device counter and the single workgroup that publishes steps + 1 at the end
+// races with nobody -- no fence, no atomics.  (Consequence: a captured hipGraph must not contain pushes.)
+__global__ __launch_bounds__(64) void push_kernel(ReplayParams P, long long steps, const uint8_t *__restrict__ frames,
                                                   const unsigned long long *__restrict__ fbits,
                                                   const uint8_t *__restrict__ a, const float *__restrict__ r,
                                                   const uint8_t *__restrict__ t) {
     const int lane = threadIdx.x;
-    const long long steps = P.dev->steps;               // transition index this push writes
     for (int e = blockIdx.x; e < P.n_envs; e += gridDim.x) {
         unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
         if (fbits) {
@@ -95,13 +97,7 @@ __global__ __launch_bounds__(64) void push_kernel(ReplayParams P, const uint8_t 
             P.act[mo] = a[e]; P.rew[mo] = r[e]; P.term[mo] = t[e];
         }
     }
-    if (lane == 0) {
-        // the last workgroup to get here publishes the step (every workgroup read `steps` above);
-        // at most 256 workgroups, so the single counter is touched at most 256 times per push
-        __threadfence();
-        const unsigned int prev = atomicAdd(&P.dev->done_ctr, 1u);
-        if (prev == gridDim.x - 1) { P.dev->done_ctr = 0; P.dev->steps = steps + 1; }
-    }
+    if (blockIdx.x == 0 && lane == 0) P.dev->steps = steps + 1;
 }
 
 // ------------------------------------------------------------------ gather (minibatch assembly)
@@ -488,6 +484,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(ReplayParams P, int n, 
 struct fb_replay {
     ReplayParams P;
     FbMT *h_mt;
+    long long host_steps;            // pushes since the last reset (mirror of ReplayDev::steps)
 };
 
 extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out) {
@@ -552,6 +549,7 @@ extern "C" int fb_replay_seed(fb_replay_t h, int rng_kind, uint64_t seed) {
 
 extern "C" int fb_replay_reset(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, void *stream) {
     FB_REQUIRE(h, "fb_replay_reset: NULL handle");
+    h->host_steps = 0;
     ReplayParams &P = h->P;
     hipStream_t st = fb_stream(stream);
     if (P.kind == FB_REPLAY_PER) {
@@ -580,9 +578,10 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
     FB_REQUIRE((frames != nullptr) != (frame_bits != nullptr), "fb_replay_push: give exactly one of frames / frame_bits");
     ReplayParams &P = h->P;
     hipStream_t st = fb_stream(stream);
-    hipLaunchKernelGGL(push_kernel, dim3(P.n_envs < 256 ? P.n_envs : 256), dim3(64), 0, st, P, frames, (const unsigned long long *)frame_bits,
+    hipLaunchKernelGGL(push_kernel, dim3(P.n_envs < 512 ? P.n_envs : 512), dim3(64), 0, st, P, h->host_steps, frames, (const unsigned long long *)frame_bits,
                        actions, rewards, terminals);
     FB_LAUNCH_CHECK();
+    h->host_steps += 1;
     if (P.kind == FB_REPLAY_PER) {
         hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(256), sizeof(UpdScratch), st, P, P.n_envs);
         FB_LAUNCH_CHECK();
