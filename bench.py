@@ -26,13 +26,14 @@ sys.path.insert(0, ROOT)
 N_ENVS, BATCH, CAPACITY = 1024, 32, 1_000_000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 # algorithmic flops / bytes per launch (n = samples in the launch)
 FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64 * 512,
             "conv3_kernel": 2 * 25 * 64 * 576, "fc1_kernel": 2 * 1600 * 512, "head_kernel": 2 * 512 * 2}
-BWD_FLOP = {"fc1_dw_kernel": 2 * 1600 * 512, "fc1_dx_kernel": 2 * 1600 * 512, "conv_dw_kernel<conv3>": 2 * 25 * 576 * 64,
-            "conv3_dx_kernel": 2 * 25 * 576 * 64, "conv_dw_kernel<conv2>": 2 * 25 * 512 * 64,
-            "conv2_dx_kernel": 2 * 25 * 512 * 64, "conv_dw_kernel<conv1>": 2 * 400 * 256 * 32}
+BWD_FLOP = {"fc1_bwd_kernel": 2 * 2 * 1600 * 512,                 # dW + dX in one launch
+            "conv3_bwd_kernel": 2 * 2 * 25 * 576 * 64, "conv2_bwd_kernel": 2 * 2 * 25 * 512 * 64,
+            "conv1_dw_kernel": 2 * 400 * 256 * 32}
 GATHER_BYTES = 102_417          # per sampled transition
 ADAM_BYTES = 28                 # per parameter
 ENV_BYTES = 6_400 + 64          # per env-step
@@ -166,12 +167,22 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / reps         # us per launch
 
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC bytes per launch, rocprofv3 --pmc passes
+        pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+
         def add(name, us, per_step, bound, work):
-            peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF
+            # conv1 runs on the bf16 matrix cores (3 bf16 MFMAs per exact fp32 product): price its
+            # ALGORITHMIC flops against the bf16 dense peak; it executes 3x that many bf16 flops
+            bf16 = name.startswith("conv1_pool_kernel")
+            peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF)
             ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
-            kernels.append({"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
-                            "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-                            "frac": round(ach / peak, 5)})
+            k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
+                 "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                 "frac": round(ach / peak, 5), "traffic": pmc.get(name)}
+            if bf16:
+                k["dtype"] = "bf16x3 (exact fp32 result)"
+                k["executed_frac"] = round(3 * ach / peak, 5)
+            kernels.append(k)
 
         scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
         scratch.init_params(seed=1)
@@ -223,12 +234,14 @@ def main():
         us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
         add("env_kernel<true>[n=1024]", us, 1, "hbm", ENV_BYTES * N_ENVS)
         dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC bytes per launch from the rocprofv3 --pmc pass
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom["kernel"].split("[")[0])
-        roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic}
+        roofline = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}
+        roofline["us"] = dom["us"]
+        if "dtype" in dom:
+            roofline["dtype"], roofline["executed_frac"] = dom["dtype"], dom["executed_frac"]
+        # the north-star HBM figure: the replay gather (102 417 logical bytes per sampled transition)
+        gk = {k["kernel"]: k for k in kernels}
+        roofline["replay_gather"] = {b: {f: gk[n][f] for f in ("achieved", "peak", "unit", "frac", "traffic", "us")}
+                                     for b, n in (("B=32", "gather_kernel<false>[B=32]"), ("B=4096", "gather_kernel<false>[B=4096]"))}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None

@@ -41,7 +41,7 @@ __device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >
 
 template <int NW>
 __device__ __forceinline__ void reduce_waves(f32x16 &acc, float *red, int wave, int lane) {
-    if (wave > 0) {
+    if (wave > 0 && wave < NW) {
 #pragma unroll
         for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
     }
@@ -387,8 +387,11 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
 __device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot, int FC, int smp, int jj, float bias, int nks) {
-    float v = hfp[(size_t)smp * FC + jj];
-    for (int ks = 1; ks < nks; ks++) v += hfp[((size_t)ks * stot + smp) * FC + jj];
+    float v = hfp[(size_t)smp * FC + jj], t[FC1_KS];
+#pragma unroll
+    for (int ks = 1; ks < FC1_KS; ks++) t[ks] = ks < nks ? hfp[((size_t)ks * stot + smp) * FC + jj] : 0.f;   // loads in flight together
+#pragma unroll
+    for (int ks = 1; ks < FC1_KS; ks++) v += t[ks];              // fixed order; + 0.f is exact
     return fmaxf(v + bias, 0.f);
 }
 
@@ -552,10 +555,10 @@ __global__ void adam_tick_kernel(AdamDev *ad) {
 
 // ================================================================== backward
 // dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
-__global__ __launch_bounds__(256) void fc1_dw_kernel(const float *__restrict__ h3, const float *__restrict__ dhf,
-                                                     float *__restrict__ grad, int B, int FC) {
+__device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h3, const float *__restrict__ dhf,
+                                            float *__restrict__ grad, int B, int FC) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int nt_n = FC / 32, tile = blockIdx.x * 4 + wave;
+    const int nt_n = FC / 32, tile = blk * 8 + wave;
     if (tile >= 50 * nt_n) return;
     const int kt = tile / nt_n, nt = tile - kt * nt_n;
     f32x16 acc = {0};
@@ -571,11 +574,10 @@ __global__ __launch_bounds__(256) void fc1_dw_kernel(const float *__restrict__ h
 }
 
 // dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 8 waves split n
-__global__ __launch_bounds__(512) void fc1_dx_kernel(const float *__restrict__ params, const float *__restrict__ h3,
-                                                     const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC) {
-    __shared__ float red[7 * 16 * 64];
+__device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ h3,
+                                            const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int mt = blockIdx.x, kt = blockIdx.y;
+    const int mt = blk / 50, kt = blk - mt * 50;
     const int m = mt * 32 + i;
     const bool ok = m < B;
     const int kh = FC / 16, nbeg = wave * (FC / 8) + hl * kh;
@@ -610,22 +612,21 @@ template <> struct DwGeom<2> { static constexpr int OH = 5, OW = 5, IH = 10, IW 
 template <> struct DwGeom<3> { static constexpr int OH = 5, OW = 5, IH = 5, IW = 5, CI = 64, CO = 64, K = 3, S = 1, P = 1, WOFF = OFF_W3, BOFF = OFF_B3, CELLS = 9, CIT = 2; };
 
 template <int LAYER>
-__global__ __launch_bounds__(512) void conv_dw_kernel(int B, const float *__restrict__ x, const uint8_t *__restrict__ xu8,
-                                                      const float *__restrict__ dy, const uint8_t *__restrict__ amax,
-                                                      float *__restrict__ slabs, size_t slab_stride) {
+__device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *red, int B, const float *__restrict__ x,
+                                             const uint8_t *__restrict__ xu8, const float *__restrict__ dy,
+                                             const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride) {
     using G = DwGeom<LAYER>;
     constexpr int COT = G::CO / 32, WTILES = G::CELLS * G::CIT * COT, OPIX = G::OH * G::OW;
-    __shared__ float red[7 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const bool bias_tile = (int)blockIdx.x >= WTILES;
-    int tile = bias_tile ? 0 : blockIdx.x;
-    const int cot = bias_tile ? (int)blockIdx.x - WTILES : tile % COT;
+    const bool bias_tile = bx >= WTILES;
+    int tile = bias_tile ? 0 : bx;
+    const int cot = bias_tile ? bx - WTILES : tile % COT;
     tile /= COT;
     const int cit = tile % G::CIT, cell = tile / G::CIT;
     const int ky = LAYER == 1 ? cell : cell / G::K, kx = LAYER == 1 ? 0 : cell - ky * G::K;
-    const int M = B * OPIX, parts = gridDim.y * 8;
+    const int M = B * OPIX, parts = nz * 8;
     int per = (M + parts - 1) / parts; per += per & 1;
-    const int mbeg = (blockIdx.y * 8 + wave) * per;
+    const int mbeg = wave < 8 ? (zslab * 8 + wave) * per : M;        // a 9th wave (merged launches) stays idle
     const int mend = mbeg + per < M ? mbeg + per : M;
     f32x16 acc = {0};
     for (int c0 = mbeg; c0 < mend; c0 += 32) {
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(512) void conv_dw_kernel(int B, const float *__rest
     }
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
-        float *o = slabs + blockIdx.y * slab_stride;
+        float *o = slabs + zslab * slab_stride;
         if (bias_tile) {
             if (hl == 0) o[G::BOFF + cot * 32 + j] = acc[0];                         // row 0 = column sums
         } else {
@@ -671,11 +672,10 @@ __global__ __launch_bounds__(512) void conv_dw_kernel(int B, const float *__rest
 }
 
 // conv3 data gradient -> dh2 (masked by relu2); 9 waves = 9 cells
-__global__ __launch_bounds__(576) void conv3_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh3,
-                                                       const float *__restrict__ h2, float *__restrict__ dh2, int B) {
-    __shared__ float red[8 * 16 * 64];
+__device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh3,
+                                              const float *__restrict__ h2, float *__restrict__ dh2, int B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = B * 25, tile = blockIdx.x, c0 = blockIdx.y * 32;
+    const int M = B * 25, tile = blk >> 1, c0 = (blk & 1) * 32;
     const int ky = wave / 3, kx = wave - ky * 3;
     const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, iy = rem / 5, ix = rem - iy * 5;
     const int oy = iy + 1 - ky, ox = ix + 1 - kx;
@@ -698,21 +698,20 @@ __global__ __launch_bounds__(576) void conv3_dx_kernel(const float *__restrict__
 // (iy, ix) only meets the 4 kernel cells with ky = iy + 1 and kx = ix + 1 (mod 2): tiles are built per parity
 // class (blockIdx.y) from the 25 pixels of that class per sample, and the 4 waves take the 4 live cells --
 // a quarter of the MFMAs a class-blind tiling would issue.
-__global__ __launch_bounds__(256) void conv2_dx_kernel(const float *__restrict__ params, const float *__restrict__ dh2,
-                                                       const float *__restrict__ p1, float *__restrict__ dp1, int B) {
-    __shared__ float red[3 * 16 * 64];
+__device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh2,
+                                              const float *__restrict__ p1, float *__restrict__ dp1, int B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = B * 25, tile = blockIdx.x, py = blockIdx.y >> 1, px = blockIdx.y & 1;
+    const int M = B * 25, tile = blk >> 2, py = (blk >> 1) & 1, px = blk & 1;
     const int ky = ((py + 1) & 1) + 2 * (wave >> 1), kx = ((px + 1) & 1) + 2 * (wave & 1);
     const int m = tile * 32 + i, b = m / 25, q = m - b * 25, qy = q / 5, qx = q - qy * 5;
     const int iy = py + 2 * qy, ix = px + 2 * qx;
     const int ty = iy + 1 - ky, tx = ix + 1 - kx;                 // even by construction
-    const bool ok = m < M && ty >= 0 && tx >= 0 && (ty >> 1) < 5 && (tx >> 1) < 5;
-    const int cell = ky * 4 + kx;
+    const bool ok = wave < 4 && m < M && ty >= 0 && tx >= 0 && (ty >> 1) < 5 && (tx >> 1) < 5;   // waves 4..7 of a merged launch idle
+    const int cell = (ky * 4 + kx) & 15;
     const float *arun = dh2 + ((size_t)b * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
     const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
     f32x16 acc = {0};
-    mma_run_run<32>(arun, ok, brun, acc);
+    if (wave < 4) mma_run_run<32>(arun, ok, brun, acc);
     reduce_waves<4>(acc, red, wave, lane);
     if (wave == 0) {
 #pragma unroll
@@ -725,6 +724,46 @@ __global__ __launch_bounds__(256) void conv2_dx_kernel(const float *__restrict__
             }
         }
     }
+}
+
+// ---- merged backward launches: the weight-gradient tiles and the data-gradient tiles of one layer are
+// independent, so they share one launch (the first n_dx workgroups run the dX body, the rest the dW body):
+// three kernel boundaries fewer per step and the two latency chains overlap.
+__global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
+                                                      const float *__restrict__ dhf, float *__restrict__ dh3,
+                                                      float *__restrict__ grad, int B, int FC) {
+    __shared__ float red[7 * 16 * 64];
+    if ((int)blockIdx.x < n_dx) fc1_dx_body(blockIdx.x, red, params, h3, dhf, dh3, B, FC);
+    else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC);
+}
+
+__global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
+                                                        const float *__restrict__ dh3, const float *__restrict__ h2,
+                                                        float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B) {
+    __shared__ float red[8 * 16 * 64];
+    if ((int)blockIdx.x < n_dx) conv3_dx_body(blockIdx.x, red, params, dh3, h2, dh2, B);
+    else {
+        const int t = blockIdx.x - n_dx;
+        conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride);
+    }
+}
+
+__global__ __launch_bounds__(512) void conv2_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
+                                                        const float *__restrict__ dh2, const float *__restrict__ p1,
+                                                        float *__restrict__ dp1, float *__restrict__ slabs, size_t slab_stride, int B) {
+    __shared__ float red[7 * 16 * 64];
+    if ((int)blockIdx.x < n_dx) conv2_dx_body(blockIdx.x, red, params, dh2, p1, dp1, B);
+    else {
+        const int t = blockIdx.x - n_dx;
+        conv_dw_body<2>(t % 34, t / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride);
+    }
+}
+
+__global__ __launch_bounds__(512) void conv1_dw_kernel(int nz, const uint8_t *__restrict__ states, const float *__restrict__ dp1,
+                                                       const uint8_t *__restrict__ amax, float *__restrict__ slabs,
+                                                       size_t slab_stride, int B) {
+    __shared__ float red[7 * 16 * 64];
+    conv_dw_body<1>(blockIdx.x % 9, blockIdx.x / 9, nz, red, B, nullptr, states, dp1, amax, slabs, slab_stride);
 }
 
 // sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
@@ -811,9 +850,6 @@ struct fb_qnet {
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
     int zmax;
-    hipStream_t side;                // weight-gradient kernels run here, beside the data-gradient chain
-    hipEvent_t ev[4];
-    int overlap;
 };
 
 static NetOff make_off(int FC, int A, int dueling) {
@@ -856,11 +892,6 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
         fb_qnet_destroy(h);
         return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
-    if (e != hipSuccess) { fb_set_error(FB_ERR_HIP, "fb_qnet_create: %s", hipGetErrorString(e)); fb_qnet_destroy(h); return FB_ERR_HIP; }
-    const char *ov = getenv("FB_QNET_OVERLAP");
-    h->overlap = ov ? atoi(ov) : 0;      // measured slower than the plain chain on MI355X (events cost more than they hide)
     *out = h;
     return fb_qnet_set_hparams(h, 1e-6f, 0.9f, 0.999f, 1e-8f);
 }
@@ -870,8 +901,6 @@ extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     void *ptrs[] = {h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return FB_OK;
 }
@@ -952,8 +981,8 @@ extern "C" int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *
 // kernel on the caller's stream (fb_qnet_profile_kernel) with exactly the launch geometry the real
 // step uses.  `only` < 0 launches the whole plan.
 enum KernelId {
-    K_CONV1 = 0, K_CONV2, K_CONV3, K_FC1, K_HEAD, K_LOSS, K_FC1_DW, K_FC1_DX, K_CONV3_DW, K_CONV3_DX, K_CONV2_DW,
-    K_CONV2_DX, K_CONV1_DW, K_SLAB, K_ADAM, K_COUNT
+    K_CONV1 = 0, K_CONV2, K_CONV3, K_FC1, K_HEAD, K_LOSS, K_FC1_BWD, K_CONV3_BWD, K_CONV2_BWD, K_CONV1_DW, K_SLAB, K_ADAM,
+    K_COUNT
 };
 
 struct Plan {
@@ -1004,31 +1033,21 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.adam = h->adam; L.tick = p.tick;
             hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
         }
-        // The weight-gradient kernels only feed Adam, the data-gradient kernels feed each other: fork the dW
-        // launches onto a side stream (events = graph edges when captured) and join before the update.
-        const bool fork = only < 0 && h->overlap;
-        hipStream_t sw = fork ? h->side : st;
-        if (fork) { (void)hipEventRecord(h->ev[0], st); (void)hipStreamWaitEvent(sw, h->ev[0], 0); }
-        FB_K(K_FC1_DW) hipLaunchKernelGGL(fc1_dw_kernel, dim3((50 * (FC / 32) + 3) / 4), dim3(256), 0, sw, h->h3, h->dhf, G, B, FC);
-        FB_K(K_FC1_DX) hipLaunchKernelGGL(fc1_dx_kernel, dim3((B + 31) / 32, 50), dim3(512), 0, st, h->params[0], h->h3, h->dhf, h->dh3, B, FC);
         // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
         int z3 = (B * 25 + 255) / 256, z1 = (B * 400 + 255) / 256;
         if (z3 > h->zmax) z3 = h->zmax;
         if (z1 > h->zmax) z1 = h->zmax;
         const int z2 = z3;
         const size_t ss = CONV_PARAMS;
-        if (fork) { (void)hipEventRecord(h->ev[1], st); (void)hipStreamWaitEvent(sw, h->ev[1], 0); }
-        FB_K(K_CONV3_DW) hipLaunchKernelGGL(conv_dw_kernel<3>, dim3(36 + 2, z3), dim3(512), 0, sw, B, h->h2, (const uint8_t *)nullptr,
-                                            h->dh3, (const uint8_t *)nullptr, h->slabs, ss);
-        FB_K(K_CONV3_DX) hipLaunchKernelGGL(conv3_dx_kernel, dim3((B * 25 + 31) / 32, 2), dim3(576), 0, st, h->params[0], h->dh3, h->h2, h->dh2, B);
-        if (fork) { (void)hipEventRecord(h->ev[2], st); (void)hipStreamWaitEvent(sw, h->ev[2], 0); }
-        FB_K(K_CONV2_DW) hipLaunchKernelGGL(conv_dw_kernel<2>, dim3(32 + 2, z2), dim3(512), 0, sw, B, h->p1, (const uint8_t *)nullptr,
-                                            h->dh2, (const uint8_t *)nullptr, h->slabs, ss);
-        if (fork) (void)hipEventRecord(h->ev[3], sw);
-        FB_K(K_CONV2_DX) hipLaunchKernelGGL(conv2_dx_kernel, dim3((B * 25 + 31) / 32, 4), dim3(256), 0, st, h->params[0], h->dh2, h->p1, h->dp1, B);
-        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv_dw_kernel<1>, dim3(8 + 1, z1), dim3(512), 0, st, B, (const float *)nullptr, p.s, h->dp1,
-                                            h->amax, h->slabs, ss);
-        if (fork) (void)hipStreamWaitEvent(st, h->ev[3], 0);
+        const int ndx1 = ((B + 31) / 32) * 50, ndw1 = (50 * (FC / 32) + 7) / 8;
+        FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+        const int ndx3 = ((B * 25 + 31) / 32) * 2;
+        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3), dim3(576), 0, st, ndx3, z3, h->params[0], h->dh3, h->h2,
+                                             h->dh2, h->slabs, ss, B);
+        const int ndx2 = ((B * 25 + 31) / 32) * 4;
+        FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
+                                             h->dp1, h->slabs, ss, B);
+        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * z1), dim3(512), 0, st, z1, p.s, h->dp1, h->amax, h->slabs, ss, B);
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
@@ -1137,8 +1156,7 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
 
 extern "C" const char *fb_qnet_kernel_name(int kernel) {
     static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv2_kernel", "conv3_kernel", "fc1_kernel", "head_kernel",
-                                         "loss_head_kernel", "fc1_dw_kernel", "fc1_dx_kernel", "conv_dw_kernel<conv3>",
-                                         "conv3_dx_kernel", "conv_dw_kernel<conv2>", "conv2_dx_kernel", "conv_dw_kernel<conv1>",
-                                         "slab_reduce_kernel", "adam_kernel"};
+                                         "loss_head_kernel", "fc1_bwd_kernel", "conv3_bwd_kernel", "conv2_bwd_kernel",
+                                         "conv1_dw_kernel", "slab_reduce_kernel", "adam_kernel"};
     return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }
