@@ -118,7 +118,9 @@ int fb_replay_seed(fb_replay_t h, int rng_kind, uint64_t seed);          /* sync
 int fb_replay_reset(fb_replay_t h, const uint8_t *frames /*[dev] u8[N,80,80] or NULL*/,
                     const uint64_t *frame_bits /*[dev] u64[N,100] or NULL*/, void *stream);
 /* setPerception's store: one transition per env (env order = deque order within a step).
- * Exactly one of frames / frame_bits is given (the NEXT observation). */
+ * Exactly one of frames / frame_bits is given (the NEXT observation).  The handle counts pushes on
+ * the host (the kernel receives the step index by value), so unlike sample / gather / train a push
+ * must not be replayed from a captured hipGraph. */
 int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
                    const float *rewards, const uint8_t *terminals, void *stream);
 /* currentState of every env: u8[N,80,80,4] [dev] (newest frame last). */
