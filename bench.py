@@ -59,10 +59,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     L.require_gpu()
-    torch.cuda.set_device(local_rank)
+    # rehearsal switches for a one-GPU box (the real multi-GPU run uses neither): all ranks on cuda:0 over gloo
+    dev_index = 0 if os.environ.get("FB_BENCH_SINGLE_DEVICE") else local_rank
+    backend = os.environ.get("FB_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
 
     def barrier():
         if world > 1:
@@ -247,7 +251,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc                    # the checker, timed as the reported baseline
-        res = orc.reference_loop(observe_steps=150, train_steps=25, replay_cap=50000, seed=0)
+        res = orc.reference_loop(observe_steps=300, train_steps=60, replay_cap=50000, seed=0)
         cpu = {"value": round(res["env_steps_per_s"], 2), "unit": "env-steps/s", "cores": 1, "kind": "port",
                "grad_steps_per_sec": round(res["grad_steps_per_s"], 3),
                "sample": f"oracle single-env loop of FlappyBirdDQN.py:72-76 (batch-1 act, full render + preprocess, "
