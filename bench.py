@@ -221,17 +221,14 @@ def main():
                 add(name, us, 1, "hbm", ADAM_BYTES * net.n_params)
             else:
                 add(name, us, 1, "hbm", 0)
-        us = ev_time(lambda: [replay.gather(idx) for _ in range(R)], R)
+        us = ev_time(lambda: L.check(lib.fb_replay_profile_gather(replay.h, BATCH, L.ptr(idx), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r),
+                                                                  L.ptr(t), R, st()), "gather"), R)
         add("gather_kernel<false>[B=32]", us, 1, "hbm", GATHER_BYTES * BATCH)
         big = torch.randint(0, 100000, (4096,), dtype=torch.int64, device="cuda")
         bigrep = [torch.empty((4096, 80, 80, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         bm = [torch.empty(4096, dtype=dt_, device="cuda") for dt_ in (torch.uint8, torch.float32, torch.uint8)]
-
-        def big_gather():
-            for _ in range(10):
-                L.check(lib.fb_replay_gather(replay.h, 4096, L.ptr(big), L.ptr(bigrep[0]), L.ptr(bigrep[1]), L.ptr(bm[0]),
-                                             L.ptr(bm[1]), L.ptr(bm[2]), st()), "gather")
-        us = ev_time(big_gather, 10)
+        us = ev_time(lambda: L.check(lib.fb_replay_profile_gather(replay.h, 4096, L.ptr(big), L.ptr(bigrep[0]), L.ptr(bigrep[1]),
+                                                                  L.ptr(bm[0]), L.ptr(bm[1]), L.ptr(bm[2]), 10, st()), "gather"), 10)
         add("gather_kernel<false>[B=4096]", us, 0, "hbm", GATHER_BYTES * 4096)
         us = ev_time(lambda: [replay.current_state() for _ in range(R)], R)
         add("gather_kernel<true>[currentState n=1024]", us, 1, "hbm", 2 * 25_600 * N_ENVS)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "fb_replay_current_state": [_vp, _vp, _vp],
     "fb_replay_sample": [_vp, _i, _vp, _vp, _vp, _vp],
     "fb_replay_gather": [_vp, _i] + [_vp] * 7,
+    "fb_replay_profile_gather": [_vp, _i] + [_vp] * 6 + [_i, _vp],
     "fb_replay_update_priorities": [_vp, _i, _vp, _vp, _vp, _vp],
     "fb_replay_size": [_vp, _vp],
     "fb_replay_per_tree": [_vp] * 5,

@@ -631,6 +631,18 @@ extern "C" int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, ui
     return FB_OK;
 }
 
+// Measurement aid for bench.py: the same gather launched `reps` times back to back on `stream`, so that HIP
+// events see the kernel and not the per-call host overhead of a Python loop.
+extern "C" int fb_replay_profile_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r,
+                                        uint8_t *t, int reps, void *stream) {
+    FB_REQUIRE(reps >= 1, "fb_replay_profile_gather: reps must be >= 1");
+    for (int i = 0; i < reps; i++) {
+        int rc = fb_replay_gather(h, batch, idx, s, s2, a, r, t, stream);
+        if (rc != FB_OK) return rc;
+    }
+    return FB_OK;
+}
+
 extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err,
                                            const float *priorities_or_null, void *stream) {
     FB_REQUIRE(h && idx && (abs_err || priorities_or_null), "fb_replay_update_priorities: NULL argument");

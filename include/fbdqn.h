@@ -132,6 +132,9 @@ int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms, int64_t *
 /* s, s2: u8[B,80,80,4]; a: u8[B]; r: f32[B]; t: u8[B]  (all [dev]) */
 int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a,
                      float *r, uint8_t *t, void *stream);
+/* Measurement aid (bench.py roofline): fb_replay_gather launched `reps` times back to back on `stream`. */
+int fb_replay_profile_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r,
+                             uint8_t *t, int reps, void *stream);
 /* Memory.batch_update(tree_idx, abs_errors): abs_err f32[B] [dev] is updated in place (+= 0.01)
  * like the reference does; priorities_or_null f32[B] [dev] injects the p values instead of
  * computing (min(|e|+0.01, 1))^0.6 on the device. */
