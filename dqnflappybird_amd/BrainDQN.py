@@ -7,8 +7,16 @@ Kept exactly as in the reference (cited lines are the reference's):
   * one shared `random` stream: random.random() / randrange per action, random.sample per train step;
   * training starts when onlineTimeStep > OBSERVE, one train step per env step :73-75;
   * loss = sum of squares (not mean) :162; target from the SAME network :205.
-Not reproduced: TensorBoard graph dump, matplotlib plots and TF checkpoints.
+Checkpoint / resume (reference :176-192,227-233): every 100 000 steps the parameters go to
+"./saved_parameters<dir_name>bird-<timeStep>.npz" (flat fp32 vectors instead of a TF Saver-V2 bundle,
+plus the Adam slots the reference also saves) and gameTimes / timeStep / epsilon are pickled, in the
+reference's order, into "bird-saved-parameters.txt" -- that file is interchangeable with the reference's.
+A new Brain restores both if they exist; like the reference, the replay memory and onlineTimeStep are
+not saved, so a resumed run observes for OBSERVE steps again.
+Not reproduced: TensorBoard graph dump and matplotlib plots.
 """
+import os
+import pickle
 import random
 
 import numpy as np
@@ -36,7 +44,8 @@ class BrainDQN:
     OBSERVE, EXPLORE, BATCH_SIZE, GAMMA = OBSERVE, EXPLORE, BATCH_SIZE, GAMMA
     INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY = INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY
 
-    def __init__(self, actionNum, gameName, backend=None, fc_width=512, verbose=True, seed=None):
+    def __init__(self, actionNum, gameName, backend=None, fc_width=512, verbose=True, seed=None,
+                 save_root="./saved_parameters"):
         self.actionNum = actionNum
         self.gameName = gameName
         if backend is None:
@@ -56,7 +65,11 @@ class BrainDQN:
         self._fc_width = fc_width
         # tf.truncated_normal is unseeded in the reference: take a seed from `random` unless one is given
         self._seed = random.getrandbits(48) if seed is None else seed
+        self.save_path = save_root + self.dir_name                      # reference :45
+        self.saved_parameters_file_path = self.save_path + self.gameName + '-saved-parameters.txt'
+        self.logs_path = "./logs_" + self.gameName + self.dir_name
         self._createQNetwork()
+        self._load_saved_parameters()
 
     def _setDirName(self):
         self.dir_name = self.DIR_NAME
@@ -69,6 +82,48 @@ class BrainDQN:
 
     def __len__(self):
         return min(self._n_stored, self.REPLAY_MEMORY)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    SAVE_EVERY = 100000                                   # reference :227
+
+    def _load_saved_parameters(self):
+        """reference :176-192: restore the newest checkpoint of this algorithm's directory, if any."""
+        marker = os.path.join(self.save_path, "checkpoint")
+        if not os.path.exists(marker):
+            if self.verbose:
+                print("Could not find old network weights")
+            return False
+        with open(marker) as f:
+            ckpt = os.path.join(self.save_path, f.read().strip())
+        z = np.load(ckpt)
+        if z["online"].size != self.net.n_params:
+            raise ValueError(f"{ckpt} holds {z['online'].size} parameters, this network has {self.net.n_params}")
+        self.net.load_params(z["online"], 0)
+        self.net.load_params(z["target"], 1)
+        self.net.set_adam_state(self._be.dev(z["adam_m"]), self._be.dev(z["adam_v"]), z["beta_pows"])
+        if self.verbose:
+            print("Successfully loaded:", ckpt)
+        if os.path.exists(self.saved_parameters_file_path) and os.path.getsize(self.saved_parameters_file_path) > 0:
+            with open(self.saved_parameters_file_path, 'rb') as f:      # own files only (see save_checkpoint)
+                self.gameTimes = pickle.load(f)
+                self.timeStep = pickle.load(f)
+                self.epsilon = pickle.load(f)
+        return True
+
+    def save_checkpoint(self):
+        """reference :227-233 (saver.save + three pickle.dump calls)."""
+        os.makedirs(self.save_path, exist_ok=True)
+        name = f"{self.gameName}-{self.timeStep}.npz"
+        m, v, pows = self.net.adam_state()
+        np.savez(os.path.join(self.save_path, name), online=self._be.host(self.net.store_params(0)),
+                 target=self._be.host(self.net.store_params(1)), adam_m=self._be.host(m), adam_v=self._be.host(v),
+                 beta_pows=np.asarray(pows, np.float32))
+        with open(os.path.join(self.save_path, "checkpoint"), "w") as f:
+            f.write(name + "\n")
+        with open(self.saved_parameters_file_path, 'wb') as f:
+            pickle.dump(self.gameTimes, f)
+            pickle.dump(self.timeStep, f)
+            pickle.dump(self.epsilon, f)
 
     # ------------------------------------------------------------------ reference surface
     def setInitState(self, observ):
@@ -144,3 +199,5 @@ class BrainDQN:
         loss, _, y = self.net.train_step(self.ALGO, s, a, r, s2, t, gamma=self.GAMMA)
         self.lost = loss
         self._last_q_target = y
+        if self.timeStep % self.SAVE_EVERY == 0:
+            self.save_checkpoint()

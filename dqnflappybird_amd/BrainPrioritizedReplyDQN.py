@@ -174,3 +174,5 @@ class BrainPrioritizedReplyDQN(BrainDQNNature):
         self.replayMemory.batch_update(tree_idx, abs_errors)
         self.lost = loss
         self._last_q_target = y
+        if self.timeStep % self.SAVE_EVERY == 0:                 # reference :320-327
+            self.save_checkpoint()

@@ -46,6 +46,19 @@ class CpuNet:
     def apply_adam(self, g):
         self.opt.step(self.p[0], g)
 
+    def load_params(self, flat, which=0):
+        self.p[which] = np.array(flat, np.float32)
+
+    def store_params(self, which=0):
+        return self.p[which].copy()
+
+    def adam_state(self):
+        return self.opt.m.copy(), self.opt.v.copy(), np.array([self.opt.b1p.value, self.opt.b2p.value], np.float32)
+
+    def set_adam_state(self, m, v, pows):
+        self.opt.m[:], self.opt.v[:] = m, v
+        self.opt.b1p.value, self.opt.b2p.value = float(pows[0]), float(pows[1])
+
 
 class CpuReplay:
     """deque semantics of BrainDQN.py:66-72 for one env (+ the oracle Memory for PER)."""

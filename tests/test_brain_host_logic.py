@@ -1,5 +1,6 @@
 """Host logic of the drop-in Brain classes on CPU (compute delegated to tests/cpu_backend.py):
 the reference's schedules and RNG consumption order (BrainDQN.py:66-116,195-223 and the variants)."""
+import os
 import random
 
 import numpy as np
@@ -20,6 +21,7 @@ def frames_source(oracle, seed):
 
 
 def make(cls, **kw):
+    kw.setdefault("save_root", "/nonexistent/saved_parameters")
     b = cls(2, 'bird', backend=CpuBackend(), verbose=False, seed=1, **kw)
     b.OBSERVE, b.BATCH_SIZE = 12., 8          # instance attributes: small so that training starts quickly
     return b
@@ -142,3 +144,27 @@ def test_hitmasks_equal_reference(golden):
     assert np.array_equal(np.array(hit["pipe"][0], np.uint8), g["hit_pipe_upper"])
     assert np.array_equal(np.array(hit["pipe"][1], np.uint8), g["hit_pipe_lower"])
     assert np.array_equal(np.array(hit["player"], np.uint8), g["hit_player"])
+
+
+def test_checkpoint_resume_roundtrip(oracle, tmp_path):
+    """reference BrainDQN.py:176-192,227-233: parameters + Adam slots + the three pickled scalars; the
+    scalar file has the reference's exact format (three consecutive pickles)."""
+    import pickle
+    from dqnflappybird_amd.BrainDQNNature import BrainDQNNature
+    first, step_env = frames_source(oracle, 8)
+    random.seed(3)
+    root = str(tmp_path / "saved_parameters")
+    a = make(BrainDQNNature, save_root=root)
+    a.SAVE_EVERY = 7
+    run(a, step_env, first, 30)                       # trains from step 13, saves at timeStep 14, 21, 28
+    assert sorted(os.listdir(root + "/dqn_nature/")) == ["bird-14.npz", "bird-21.npz", "bird-28.npz",
+                                                          "bird-saved-parameters.txt", "checkpoint"]
+    with open(root + "/dqn_nature/bird-saved-parameters.txt", "rb") as f:
+        game_times, time_step, eps = pickle.load(f), pickle.load(f), pickle.load(f)
+    assert time_step == 28 and isinstance(game_times, int) and 0.0299 < eps < 0.03
+    b = make(BrainDQNNature, save_root=root)          # a fresh Brain picks the newest checkpoint up
+    assert (b.timeStep, b.gameTimes, b.epsilon) == (time_step, game_times, eps) and b.onlineTimeStep == 0
+    z = np.load(root + "/dqn_nature/bird-28.npz")
+    assert np.array_equal(b.net.p[0], z["online"]) and np.array_equal(b.net.p[1], z["target"])
+    assert np.array_equal(b.net.opt.m, z["adam_m"]) and b.net.opt.b1p.value == z["beta_pows"][0]
+    assert not np.array_equal(z["online"], oracle.init_params(b.net.cfg, 1))     # it really trained

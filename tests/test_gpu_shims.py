@@ -124,3 +124,26 @@ def test_vecbrain_device_resident_loop(torch_cuda, algo):
     assert vb.timeStep == 40 and len(vb.replay) == 40 * 64
     assert np.isfinite(vb.last_loss.item())
     assert int(vb.episodes.item()) >= 0
+
+
+def test_checkpoint_resume_on_device(torch_cuda, oracle, tmp_path):
+    """save_checkpoint / _load_saved_parameters through the HIP backend (reference BrainDQN.py:176-192,227-233)."""
+    from dqnflappybird_amd.BrainDQN import BrainDQN
+    from tests.test_brain_host_logic import frames_source
+    first, step_env = frames_source(oracle, 2)
+    root = str(tmp_path / "saved_parameters")
+    a = BrainDQN(2, 'bird', verbose=False, seed=5, save_root=root)
+    a.OBSERVE, a.BATCH_SIZE = 8., 8
+    a.setInitState(first)
+    for _ in range(14):
+        act = a.getAction()
+        obs, r, t, s = step_env(int(act[1]))
+        a.setPerception(obs, act, r, t, s)
+    a.save_checkpoint()
+    b = BrainDQN(2, 'bird', verbose=False, seed=99, save_root=root)
+    assert torch_cuda.equal(a.net.store_params(0), b.net.store_params(0))
+    assert torch_cuda.equal(a.net.adam_state()[0], b.net.adam_state()[0])
+    assert (b.timeStep, b.epsilon, b.gameTimes) == (a.timeStep, a.epsilon, a.gameTimes)
+    # the restored net computes the same Q (incl. the refreshed bf16 split of conv1)
+    st = torch_cuda.from_numpy(a.currentState[None]).cuda()
+    assert torch_cuda.equal(a.net.forward(st), b.net.forward(st))
