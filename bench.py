@@ -7,7 +7,7 @@
 
 Workload (BASELINE.json configs[1]): per GPU 1024 vectorised envs + BrainDQN (uniform replay,
 1 M-slot ring, batch 32, fp32).  One *step* = one pass of the whole hot path over one batch of
-envs: currentState -> getAction for 1024 envs (forward + epsilon-greedy) -> frame_step (render +
+envs: getAction for 1024 envs from their currentState (forward + epsilon-greedy) -> frame_step (render +
 preprocess fused) -> store -> random.sample(32) -> minibatch gather -> _trainQNetwork (target
 forward, forward, backward, Adam; with N > 1 one RCCL all-reduce of the flat gradient).
 `value` = env-steps/s over all ranks in that loop.  The train-only leg (sample -> gather -> train)
@@ -81,6 +81,7 @@ def main():
     net = QNet(2, 512, "plain", max_batch=N_ENVS)
     net.init_params(seed=seed)                              # identical replicas on every rank
     grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda") if world > 1 else None
+    nib = env.track_state()                                 # agents' 4-frame stacks, kept by the env kernel
     env.observe()
     replay.reset(env.frame_bits)
     eps = 0.03                                              # INITIAL_EPSILON (BrainDQN.py:25)
@@ -96,8 +97,7 @@ def main():
             net.train_step("dqn", s, a, r, s2, t, want_aux=False)
 
     def full_step(step):
-        states = replay.current_state()
-        actions = net.act(states, eps, seed=seed + rank, step=step)
+        actions = net.act_nib(nib, eps, seed=seed + rank, step=step)      # currentState never leaves nibble form
         env.frame_step(actions, want_u8=False)
         replay.push(env.frame_bits, actions, env.reward, env.terminal)
         train(step)
@@ -199,10 +199,10 @@ def main():
         lib = L.lib()
         st = L.current_stream
         # acting forward, n = 1024
-        scratch.act(states, 0.0)
+        scratch.act_nib(nib, 0.0)
         for k in range(5):
             name = lib.fb_qnet_kernel_name(k).decode()
-            us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -1, N_ENVS, L.ptr(states), None, None, None,
+            us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
                                                                   None, None, st()), "profile"), R)
             add(name + "[act n=1024]", us, 1, "mfma", FWD_FLOP[name] * N_ENVS)
         # train step, B = 32 (forward kernels see 2B samples: s and s')
@@ -231,7 +231,7 @@ def main():
                                                                   L.ptr(bm[0]), L.ptr(bm[1]), L.ptr(bm[2]), 10, st()), "gather"), 10)
         add("gather_kernel<false>[B=4096]", us, 0, "hbm", GATHER_BYTES * 4096)
         us = ev_time(lambda: [replay.current_state() for _ in range(R)], R)
-        add("gather_kernel<true>[currentState n=1024]", us, 1, "hbm", 2 * 25_600 * N_ENVS)
+        add("gather_kernel<true>[currentState n=1024]", us, 0, "hbm", 2 * 25_600 * N_ENVS)
         us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
         add("env_kernel<true>[n=1024]", us, 1, "hbm", ENV_BYTES * N_ENVS)
         dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])

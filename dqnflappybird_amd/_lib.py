@@ -35,6 +35,7 @@ SIGNATURES = {
     "fb_env_set_gap_tape": [_vp, _vp, _i],
     "fb_env_render_full": [_vp, _i, _vp, _vp],
     "fb_env_error_count": [_vp, _vp],
+    "fb_env_set_nib_buffer": [_vp, _vp],
     "fb_preprocess_rgb": [_vp, _vp, _i, _vp, _vp],
     "fb_replay_create": [_i64, _i, _i, _vp],
     "fb_replay_destroy": [_vp],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "fb_qnet_set_hparams": [_vp, _f, _f, _f, _f],
     "fb_qnet_forward": [_vp, _i, _vp, _i, _vp, _vp],
     "fb_qnet_act": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],
+    "fb_qnet_act_nib": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],
     "fb_qnet_train_step": [_vp, _i, _i] + [_vp] * 6 + [_d] + [_vp] * 5,
     "fb_qnet_apply_adam": [_vp, _vp, _vp],
     "fb_qnet_sync_target": [_vp, _vp],

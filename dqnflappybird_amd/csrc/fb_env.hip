@@ -48,6 +48,7 @@ struct EnvParams {
     int32_t *state;                      // [n_envs][16]
     const EnvConst *cst;
     unsigned long long *err_count;
+    uint8_t *nib;                        // optional [n_envs][3200]: 2 pixels x last 4 frames per byte (caller owned)
 };
 
 // ------------------------------------------------------------------ device helpers
@@ -256,6 +257,19 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
         }
         __syncthreads();
         if (frame_bits) for (int w = threadIdx.x; w < 100; w += 256) frame_bits[(size_t)env * 100 + w] = fw[w];
+        if (p.nib) {
+            // the agent's 4-frame stack (BrainDQN.py:68,238-239: newest last, never reset) as one nibble per pixel:
+            // bit f of a pixel's nibble = frame f of the stack; a step shifts the nibbles down and puts the new
+            // frame on top, the initial observation fills all four frames.  One u32 = 8 pixels.
+            uint32_t *dst = reinterpret_cast<uint32_t *>(p.nib + (size_t)env * 3200);
+            for (int w = threadIdx.x; w < 800; w += 256) {
+                const unsigned t = (unsigned)(fw[w >> 3] >> ((w & 7) * 8)) & 0xFFu;       // the 8 new pixel bits
+                uint32_t top = 0;
+#pragma unroll
+                for (int m = 0; m < 8; m++) top |= ((t >> m) & 1u) << (4 * m + 3);
+                dst[w] = STEP ? (((dst[w] >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
+            }
+        }
         if (frames) {
             for (int q = threadIdx.x; q < 1600; q += 256) {                       // 4 pixels -> one 32-bit store
                 const unsigned int nib = (unsigned int)(fw[q >> 4] >> ((q & 15) * 4)) & 0xFu;
@@ -491,6 +505,13 @@ extern "C" int fb_preprocess_rgb(fb_env_t h, const uint8_t *rgb, int n_frames, u
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, fb_stream(stream), h->d_const, rgb, n_frames, out);
     FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_env_set_nib_buffer(fb_env_t h, uint8_t *nib_states) {
+    FB_REQUIRE(h, "fb_env_set_nib_buffer: NULL handle");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    h->p.nib = nib_states;
     return FB_OK;
 }
 

@@ -186,7 +186,24 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 
 // conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2; one wave per tile of 8 pooled pixels x 4
 // window positions (the pool is a max over 4 accumulator registers of one lane), 48 bf16 MFMAs per tile.
+// NIB = false: states are u8[n][80][80][4] (the reference's layout).  NIB = true (acting path): states are
+// the env kernel's running "nibble state" u8[n][80][40]: one byte = 2 horizontally adjacent pixels x the
+// last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
+// bf16x8 operand comes out of a 256-entry LDS table with one ds_read_b128 -- no u8 -> bf16 conversion, and
+// the 25.6 KB/env currentState expansion (its own launch before) disappears.
+template <bool NIB>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
+    __shared__ uint4 lut[NIB ? 256 : 1];
+    if (NIB) {
+        const unsigned t = threadIdx.x;                       // element j = 4*px + f  <->  bit j of the byte; 255.0 = 0x437F
+        uint4 e;
+        e.x = ((t >> 0) & 1u) * 0x437Fu | ((t >> 1) & 1u) * 0x437F0000u;
+        e.y = ((t >> 2) & 1u) * 0x437Fu | ((t >> 3) & 1u) * 0x437F0000u;
+        e.z = ((t >> 4) & 1u) * 0x437Fu | ((t >> 5) & 1u) * 0x437F0000u;
+        e.w = ((t >> 6) & 1u) * 0x437Fu | ((t >> 7) & 1u) * 0x437F0000u;
+        lut[t] = e;
+        __syncthreads();
+    }
     const Slice s = sl.s[blockIdx.z];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int npool = s.count * 100, tile = blockIdx.x * 4 + wave;
@@ -200,13 +217,21 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
     for (int ky = 0; ky < 8; ky++) {
         const int iy = oy * 4 + ky - 2;
         const bool rowok = P < npool && iy >= 0 && iy < 80;
-        const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * 4;
+        const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * (NIB ? 1 : 8) / 2;
 #pragma unroll
         for (int kq = 0; kq < 2; kq++) {
             const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;         // even: the pixel pair is inside or outside together
-            uint2 v = make_uint2(0u, 0u);
-            if (rowok && ix >= 0 && ix < 80) v = *reinterpret_cast<const uint2 *>(row + (size_t)ix * 4);
-            const bf16x8 A = u8x8_to_bf16(v);
+            const bool ok = rowok && ix >= 0 && ix < 80;
+            bf16x8 A;
+            if (NIB) {
+                unsigned idx = 0;                                // entry 0 = all zero = the SAME padding
+                if (ok) idx = row[ix >> 1];
+                A = __builtin_bit_cast(bf16x8, lut[idx]);
+            } else {
+                uint2 v = make_uint2(0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint2 *>(row + (size_t)ix * 4);
+                A = u8x8_to_bf16(v);
+            }
 #pragma unroll
             for (int part = 0; part < 3; part++) {
                 const uint4 wv = WB[((part * 8 + ky) * 2 + kq) * 64];
@@ -987,6 +1012,7 @@ enum KernelId {
 
 struct Plan {
     Slices sl; int ns;                       // forward slices
+    bool nib;                                // states are the env's nibble state (acting path)
     uint8_t *actions; float epsilon; uint64_t seed, step;
     bool train;                              // forward only when false
     int algo, B; const uint8_t *s, *a, *t; const float *r, *isw; double gamma;
@@ -1000,7 +1026,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
     const bool big = maxc >= 256;
     const int t1 = (maxc * 100 + 7) / 8, t23 = (maxc * 25 + 31) / 32;
-    FB_K(K_CONV1) hipLaunchKernelGGL(conv1_pool_kernel, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+    FB_K(K_CONV1) {
+        if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+        else hipLaunchKernelGGL(conv1_pool_kernel<false>, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+    }
     FB_K(K_CONV2) {
         if (big) hipLaunchKernelGGL(conv2_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->p1, h->h2);
         else hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
@@ -1087,6 +1116,19 @@ extern "C" int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsi
     return FB_OK;
 }
 
+extern "C" int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
+                               uint8_t *actions, float *q, void *stream) {
+    FB_REQUIRE(h && nib_states && actions, "fb_qnet_act_nib: NULL argument");
+    FB_REQUIRE(n >= 1 && n <= 3 * h->max_batch, "fb_qnet_act_nib: n %d exceeds 3*max_batch", n);
+    Plan p = forward_plan(h, 0, nib_states, n);
+    p.nib = true;
+    p.actions = actions; p.epsilon = epsilon; p.seed = seed; p.step = step;
+    int rc = run_plan(h, p, -1, fb_stream(stream));
+    if (rc != FB_OK) return rc;
+    if (q) FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)n * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    return FB_OK;
+}
+
 extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream) {
     FB_REQUIRE(h && flat_grad, "fb_qnet_apply_adam: NULL argument");
     hipStream_t st = fb_stream(stream);
@@ -1147,6 +1189,7 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
     if (algo < 0) {                              // the acting forward: one slice of B states through the online net
         FB_REQUIRE(h && s && B >= 1 && B <= 3 * h->max_batch && kernel <= K_HEAD, "fb_qnet_profile_kernel: bad forward request");
         p = forward_plan(h, 0, s, B);
+        p.nib = algo == -2;                      // -2: `s` is the env kernel's nibble state
     } else rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, 0.99, loss, nullptr, nullptr, nullptr, &p);
     if (rc != FB_OK) return rc;
     p.tick = false;

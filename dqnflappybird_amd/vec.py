@@ -59,6 +59,13 @@ class VecGameState:
                                     L.current_stream()), "fb_env_step")
         return (self.frames if want_u8 else None), self.reward, self.terminal, self.score
 
+    def track_state(self):
+        """Keep the agents' 4-frame stacks on the device in nibble form (fb_env_set_nib_buffer); returns the
+        u8[N,3200] tensor that QNet.act_nib consumes.  Call before observe()."""
+        self.nib = torch.zeros((self.n, 3200), dtype=torch.uint8, device=self.device)
+        L.check(L.lib().fb_env_set_nib_buffer(self.h, L.ptr(self.nib)), "fb_env_set_nib_buffer")
+        return self.nib
+
     def observe(self):
         L.check(L.lib().fb_env_observe(self.h, L.ptr(self.frames), L.ptr(self.frame_bits), L.current_stream()),
                 "fb_env_observe")
@@ -272,6 +279,16 @@ class QNet:
         q = self._get(f"qa{n}", (n, self.A), torch.float32) if want_q else None
         L.check(L.lib().fb_qnet_act(self.h, L.ptr(states), n, float(epsilon), seed, step, L.ptr(actions), L.ptr(q),
                                     L.current_stream()), "fb_qnet_act")
+        return (actions, q) if want_q else actions
+
+    def act_nib(self, nib_states, epsilon, seed=0, step=0, want_q=False):
+        """getAction for N envs straight from VecGameState.track_state()'s nibble states."""
+        _dev_check(nib_states)
+        n = nib_states.shape[0]
+        actions = self._get(f"act{n}", (n,), torch.uint8)
+        q = self._get(f"qa{n}", (n, self.A), torch.float32) if want_q else None
+        L.check(L.lib().fb_qnet_act_nib(self.h, L.ptr(nib_states), n, float(epsilon), seed, step, L.ptr(actions), L.ptr(q),
+                                        L.current_stream()), "fb_qnet_act_nib")
         return (actions, q) if want_q else actions
 
     def train_step(self, algo, s, a, r, s2, t, isw=None, gamma=0.99, flat_grad=None, want_aux=True):

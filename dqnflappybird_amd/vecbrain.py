@@ -35,6 +35,7 @@ class VecBrain:
         self.grad = torch.zeros(self.net.n_params, dtype=torch.float32, device="cuda") if world > 1 else None
         self.timeStep = 0
         self.onlineTimeStep = 0
+        self.nib = self.env.track_state()                    # currentState of every env, maintained by the env kernel
         self.env.observe()
         self.replay.reset(self.env.frame_bits)
         self.episodes = torch.zeros((), dtype=torch.int64, device="cuda")
@@ -55,8 +56,7 @@ class VecBrain:
         self.last_loss = loss
 
     def step(self):
-        states = self.replay.current_state()
-        actions = self.net.act(states, self.epsilon, seed=self.seed + self.rank, step=self.timeStep)
+        actions = self.net.act_nib(self.nib, self.epsilon, seed=self.seed + self.rank, step=self.timeStep)
         if self.epsilon > self.final_epsilon and self.onlineTimeStep > self.observe:
             self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
         _, reward, terminal, _ = self.env.frame_step(actions, want_u8=False)

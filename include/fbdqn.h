@@ -86,6 +86,12 @@ int fb_env_set_state(fb_env_t h, const int32_t *state_host);
 int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len);
 /* pygame.surfarray.array3d of one env: u8[288,512,3] [dev] (debug / parity). */
 int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream);
+/* Register (or clear with NULL) a caller-owned buffer u8[N][3200] [dev] that every following fb_env_observe /
+ * fb_env_step keeps equal to the agent's 4-frame stack (BrainDQN.py:68,238-239) in "nibble" form: byte q of an
+ * env = pixels 2q, 2q+1 (row-major 80x80), bit 4*px + f = frame f of the stack (f = 3 newest).  observe fills
+ * all four frames with the observation (setInitState); a step shifts and appends.  fb_qnet_act_nib consumes it,
+ * which removes the currentState expansion from the acting path.  Synchronous. */
+int fb_env_set_nib_buffer(fb_env_t h, uint8_t *nib_states);
 /* number of invalid actions seen so far (synchronous). */
 int fb_env_error_count(fb_env_t h, int64_t *count_host);
 /* preprocess() of FlappyBirdDQN.py:31-34 (cv2.resize -> BGR2GRAY -> threshold) for frames the caller
@@ -190,6 +196,9 @@ int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsilon, uint64
  *   flat_grad NULL : gradients are applied with Adam at once (single GPU)
  *   flat_grad [dev] f32[n_params]: gradients are only written there (data parallel: all-reduce
  *             them, then fb_qnet_apply_adam) */
+/* fb_qnet_act on the env kernel's nibble states u8[n][3200] (fb_env_set_nib_buffer) */
+int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
+                    uint8_t *actions, float *q, void *stream);
 int fb_qnet_train_step(fb_qnet_t h, int algo, int batch, const uint8_t *s, const uint8_t *a, const float *r,
                        const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
                        float *abs_err, float *q_target, float *flat_grad, void *stream);
@@ -198,7 +207,7 @@ int fb_qnet_sync_target(fb_qnet_t h, void *stream);
 /* Measurement aid (bench.py roofline): re-launch ONE kernel of the train-step plan `reps` times on
  * `stream` with the geometry the real step uses, on the workspace a preceding fb_qnet_train_step
  * of the same shape left behind.  Kernel ids count from 0; fb_qnet_kernel_name() returns "" past the
- * last one.  The Adam kernel really updates the parameters: use a scratch network. */
+ * last one.  algo = -1 / -2 selects the acting forward (batch states as u8 / as nibble states).  The Adam kernel really updates the parameters: use a scratch network. */
 int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int algo, int batch, const uint8_t *s, const uint8_t *a,
                            const float *r, const uint8_t *s2, const uint8_t *t, float *loss, void *stream);
 const char *fb_qnet_kernel_name(int kernel);

@@ -147,3 +147,33 @@ def test_checkpoint_resume_on_device(torch_cuda, oracle, tmp_path):
     # the restored net computes the same Q (incl. the refreshed bf16 split of conv1)
     st = torch_cuda.from_numpy(a.currentState[None]).cuda()
     assert torch_cuda.equal(a.net.forward(st), b.net.forward(st))
+
+
+def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cuda):
+    """The env kernel's running 4-frame nibble state == the replay ring's currentState (BrainDQN.py:68,238-239),
+    and the acting forward that consumes it gives bit-identical Q / actions to the u8 path."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+    N = 300                                   # >= 256: the large-batch kernels
+    env, rep, net = VecGameState(N, seed=3), VecReplay(5000, N), QNet(max_batch=N)
+    net.init_params(seed=1)
+    nib = env.track_state()
+    env.observe()
+    rep.reset(env.frame_bits)
+
+    def unpack(nibt):
+        b = nibt.cpu().numpy()                                     # [N][3200]
+        px = np.stack([b & 0x0F, b >> 4], axis=-1).reshape(N, 6400)   # nibble per pixel
+        return (((px[..., None] >> np.arange(4)) & 1) * 255).astype(np.uint8).reshape(N, 80, 80, 4)
+
+    rng = np.random.default_rng(0)
+    for t in range(12):
+        states = rep.current_state()
+        assert np.array_equal(unpack(nib), states.cpu().numpy()), t
+        a0, q0 = net.act(states, 0.0, want_q=True)
+        a0, q0 = a0.clone(), q0.clone()
+        a1, q1 = net.act_nib(nib, 0.0, want_q=True)
+        assert torch.equal(q0, q1) and torch.equal(a0, a1)
+        acts = torch.from_numpy((rng.random(N) < 0.2).astype(np.uint8)).cuda()
+        env.frame_step(acts, want_u8=False)
+        rep.push(env.frame_bits, acts, env.reward, env.terminal)
