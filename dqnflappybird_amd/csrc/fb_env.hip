@@ -6,7 +6,7 @@
 //   checkCrash / pixelCollision       game/wrapped_flappy_bird.py:244-300
 //   preprocess                        FlappyBirdDQN.py:31-34
 //
-// Design (DESIGN.md "Kernel E"):  one 256-thread workgroup walks envs e = blockIdx.x, +gridDim.x.
+// Design (DESIGN.md "Kernel E"):  one 512-thread workgroup walks envs e = blockIdx.x, +gridDim.x.
 // The pipe / bird sprites (palette indices), the palette, the resize tap tables and a
 // pre-rendered table of the ground region live in LDS (25 KB, staged once per workgroup).
 // The 288x512x3 canvas of the reference is never built: every output pixel of the 80x80
@@ -16,12 +16,14 @@
 // pipes, bird never below y = 403), so they depend on basex alone (12 values) and come from a
 // table computed at create time.  Pixels are emitted 64 at a time as one ballot word (the replay
 // ring stores 1 bit / pixel) and optionally as u8 {0,255}.
+#include <stdlib.h>
 #include "fb_common.h"
 
 namespace {
 
 constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H = 24;
 constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
+constexpr int ENV_THREADS = 512;  // 8 waves: the 80 output rows of an env are rendered 8 at a time
 constexpr int GROUND_C0 = 63;    // first observation column whose taps all lie in the ground sprite
 constexpr size_t BLOB_BYTES = 8 + 4 + 1024 + PIPE_H * PIPE_W + 3 * BIRD_H * BIRD_W + BASE_H * BASE_W;
 
@@ -111,7 +113,7 @@ __device__ __forceinline__ int resize_gray_bit(uint32_t s00, uint32_t s01, uint3
 
 // ------------------------------------------------------------------ the step kernel
 template <bool STEP>
-__global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
+__global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ frame_bits,
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
-        for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += ENV_THREADS) dst[i] = src[i];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
                 // pixel-exact pipe collision, :255-273 -- every bird pixel against the pipe on top of it
                 int hit = 0;
                 if (!ground) {
-                    for (int i = threadIdx.x; i < BIRD_W * BIRD_H; i += 256) {
+                    for (int i = threadIdx.x; i < BIRD_W * BIRD_H; i += ENV_THREADS) {
                         const int bx = i % BIRD_W, by = i / BIRD_W;
                         if (L.bird[(st[2] * BIRD_H + by) * BIRD_W + bx]) {
                             const int y = st[0] + by;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
         // are all background and skip the per-pixel work.  The 80 bits of a row are OR-ed into the frame's 100
         // packed words in LDS (a row straddles two or three words), then written out coalesced.
         const int gidx = (-st[4]) >> 2;                           // basex in {0,-4,..,-44}
-        for (int w = threadIdx.x; w < 100; w += 256) fw[w] = 0ull;
+        for (int w = threadIdx.x; w < 100; w += ENV_THREADS) fw[w] = 0ull;
         __syncthreads();
         const int py = __builtin_amdgcn_readfirstlane(st[0]), pidx = __builtin_amdgcn_readfirstlane(st[2]);
         const int npipes = __builtin_amdgcn_readfirstlane(st[6]);
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
 #pragma unroll
         for (int i = 0; i < 3; i++) { pxs[i] = __builtin_amdgcn_readfirstlane(st[7 + i]); gys[i] = gap_y(__builtin_amdgcn_readfirstlane(st[10 + i])); }
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        for (int r = wv; r < OBS; r += 4) {
+        for (int r = wv; r < OBS; r += ENV_THREADS / 64) {
             const int x0 = L.xo[r];
             int bcol[2], pcol[2], pgy[2];                         // per x tap: bird column / pipe column (or -1) and its gap
             bool any = false;
@@ -256,13 +258,13 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
             }
         }
         __syncthreads();
-        if (frame_bits) for (int w = threadIdx.x; w < 100; w += 256) frame_bits[(size_t)env * 100 + w] = fw[w];
+        if (frame_bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) frame_bits[(size_t)env * 100 + w] = fw[w];
         if (p.nib) {
             // the agent's 4-frame stack (BrainDQN.py:68,238-239: newest last, never reset) as one nibble per pixel:
             // bit f of a pixel's nibble = frame f of the stack; a step shifts the nibbles down and puts the new
             // frame on top, the initial observation fills all four frames.  One u32 = 8 pixels.
             uint32_t *dst = reinterpret_cast<uint32_t *>(p.nib + (size_t)env * 3200);
-            for (int w = threadIdx.x; w < 800; w += 256) {
+            for (int w = threadIdx.x; w < 800; w += ENV_THREADS) {
                 const unsigned t = (unsigned)(fw[w >> 3] >> ((w & 7) * 8)) & 0xFFu;       // the 8 new pixel bits
                 uint32_t top = 0;
 #pragma unroll
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p, const uint8_t *__
             }
         }
         if (frames) {
-            for (int q = threadIdx.x; q < 1600; q += 256) {                       // 4 pixels -> one 32-bit store
+            for (int q = threadIdx.x; q < 1600; q += ENV_THREADS) {                       // 4 pixels -> one 32-bit store
                 const unsigned int nib = (unsigned int)(fw[q >> 4] >> ((q & 15) * 4)) & 0xFu;
                 const unsigned int v = ((nib & 1u) * 0xFFu) | (((nib >> 1) & 1u) * 0xFF00u) | (((nib >> 2) & 1u) * 0xFF0000u) |
                                        (((nib >> 3) & 1u) * 0xFF000000u);
@@ -419,6 +421,7 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
     h->p.seed_lo = (uint32_t)seed; h->p.seed_hi = (uint32_t)(seed >> 32);
     h->p.cst = h->d_const;
     h->grid = n_envs < 2048 ? n_envs : 2048;
+    if (const char *g = getenv("FB_ENV_GRID")) { int v = atoi(g); if (v > 0 && v < h->grid) h->grid = v; }   // tuning knob
     *out = h;
     return fb_env_reset(h, nullptr);
 }
@@ -443,7 +446,7 @@ extern "C" int fb_env_reset(fb_env_t h, void *stream) {
 extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
                            uint8_t *terminal, int32_t *score, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
-    hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid), dim3(256), 0, fb_stream(stream), h->p, actions, frames,
+    hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p, actions, frames,
                        (unsigned long long *)frame_bits, reward, terminal, score);
     FB_LAUNCH_CHECK();
     return FB_OK;
@@ -451,7 +454,7 @@ extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, 
 
 extern "C" int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits, void *stream) {
     FB_REQUIRE(h && (frames || frame_bits), "fb_env_observe: NULL argument");
-    hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(256), 0, fb_stream(stream), h->p,
+    hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p,
                        (const uint8_t *)nullptr, frames, (unsigned long long *)frame_bits, (float *)nullptr,
                        (uint8_t *)nullptr, (int32_t *)nullptr);
     FB_LAUNCH_CHECK();
