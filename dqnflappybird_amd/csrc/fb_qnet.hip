@@ -156,6 +156,14 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float x) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
+// x = hi + mid + lo exactly, each a bf16 (round to nearest even at every step)
+__device__ __forceinline__ void split3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    hi = f32_to_bf16_rn(x);
+    const float r1 = x - __uint_as_float(hi << 16);
+    mid = f32_to_bf16_rn(r1);
+    lo = f32_to_bf16_rn(r1 - __uint_as_float(mid << 16));
+}
+
 __device__ __forceinline__ void split_w1(const float w, int idx /* flat index in W_conv1[8][8][4][32] */, uint16_t *__restrict__ w1s) {
     const int co = idx & 31, f = (idx >> 5) & 3, kx = (idx >> 7) & 7, ky = idx >> 10;
     const int kq = kx >> 2, h = (kx >> 1) & 1, j = (kx & 1) * 4 + f;
@@ -191,8 +199,11 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 // last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
 // bf16x8 operand comes out of a 256-entry LDS table with one ds_read_b128 -- no u8 -> bf16 conversion, and
 // the 25.6 KB/env currentState expansion (its own launch before) disappears.
-template <bool NIB>
-__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
+// SP = true (split-bf16 inference path): the pooled output is written as three bf16 planes p1s[plane][pixel][32]
+// and no argmax is kept (there is no backward).
+template <bool NIB, bool SP>
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax,
+                                                         uint16_t *__restrict__ p1s, size_t p1plane, int nsplit) {
     __shared__ uint4 lut[NIB ? 256 : 1];
     if (NIB) {
         const unsigned t = threadIdx.x;                       // element j = 4*px + f  <->  bit j of the byte; 255.0 = 0x437F
@@ -252,7 +263,12 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
         const int Pp = tile * 8 + 2 * g + hl;
         if (Pp < npool) {
             const size_t o = ((size_t)s.s_off * 100 + Pp) * 32 + j;
-            p1[o] = bv; amax[o] = (uint8_t)best;
+            if (SP) {
+                uint32_t hi, mid, lo;
+                split3(bv, hi, mid, lo);
+                p1s[o] = (uint16_t)hi;
+                if (nsplit == 3) { p1s[p1plane + o] = (uint16_t)mid; p1s[2 * p1plane + o] = (uint16_t)lo; }
+            } else { p1[o] = bv; amax[o] = (uint8_t)best; }
         }
     }
 }
@@ -407,6 +423,187 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
     for (int r = 0; r < 16; r++) {
         const int mr = tile * 32 + drow(r, lane);
         if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
+    }
+}
+
+// ---- split-bf16 inference path (forward only, >= 256 states: the acting path).
+// An fp32 value is the exact sum of three bf16 numbers hi + mid + lo (8 + 8 + 8 significand bits), so an fp32
+// product a*w is the sum of nine bf16 x bf16 products, each exact in the MFMA's fp32 accumulator.  The six
+// largest (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) carry everything above 2^-24 relative, the same
+// order as one fp32 rounding, and six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles per 16 k) replace eight
+// v_mfma_f32_32x32x2_f32 (8 x 64 cycles) while leaving the vector ALU to the address arithmetic.
+// Activations travel between the layers as three bf16 planes [plane][row][channel]; the weights are
+// re-split (wsplit_kernel) whenever the parameters changed: wsp[k/8][plane][N] x 8 bf16 (16 B).
+// NS = 3: the fp32-equivalent path; NS = 1 uses the hi planes only = plain bf16 inference.
+constexpr int WSP_W2 = 0, WSP_W3 = 64 * 3 * 64, WSP_WF1 = WSP_W3 + 72 * 3 * 64;     // uint4 offsets inside wsp
+
+__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *W; uint4 *out; int N;
+    if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
+    else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
+    else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
+    const int k8 = id / N, col = id - k8 * N;
+    uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) split3(W[(size_t)(k8 * 8 + e) * N + col], hi[e], mid[e], lo[e]);
+    uint4 *o = out + (size_t)k8 * 3 * N + col;
+    o[0] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[4] | hi[5] << 16, hi[6] | hi[7] << 16);
+    o[N] = make_uint4(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16, mid[4] | mid[5] << 16, mid[6] | mid[7] << 16);
+    o[2 * N] = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
+}
+
+#ifndef FB_SP_ABL
+#define FB_SP_ABL 0
+#endif
+#ifndef FB_SPG
+#define FB_SPG 2
+#endif
+constexpr int SPG = FB_SPG;
+
+struct SpArgs {
+    const uint16_t *ain; size_t aplane;      // input planes [3][rows][C] bf16
+    const uint4 *w;                          // this layer's split weights
+    const float *bias;
+    uint16_t *outp; size_t oplane;           // LAYER 2, 3: relu(acc + bias) as planes [3][M][64]
+    float *hfp; int stot;                    // LAYER 4: fp32 partial sums hfp[ks][sample][N]
+    int M, N;
+};
+
+// One workgroup = 128 output rows x 64 columns, 4 waves x (32 rows x 2 column tiles); K in chunks of 32:
+// the weight chunk (4 k-octets x NS planes x 64 columns x 16 B) goes global -> registers -> LDS (two buffers, one
+// barrier per chunk) and is shared by the four waves; the activation fragments (an im2col gather of 16-byte
+// channel runs) go straight to registers one chunk ahead.
+// LAYER 2: conv2 4x4x32->64 stride 2 (16 chunks = taps); LAYER 3: conv3 3x3x64->64 (18 chunks = half taps);
+// LAYER 4: fc1, K = 1600 = FC1_KS slices x 10 chunks, partial sums like fc1_kernel.
+// G groups of 4 waves share the K loop (group g takes chunks g, g + G, ...) so that every SIMD has G waves to
+// hide the operand latency behind; their accumulators meet in LDS at the end, summed in group order.
+template <int LAYER, int NS, int G>
+__global__ __launch_bounds__(256 * G) void sp_gemm_kernel(SpArgs a) {
+    constexpr int NCH = LAYER == 2 ? 16 : LAYER == 3 ? 18 : 10, NIT = NCH / G;
+    static_assert(NCH % G == 0, "chunks must divide over the wave groups");
+    constexpr int BSZ = 2 * 4 * NS * 64, RSZ = (G - 1) * 4 * 32 * 64 / 4;        // uint4 units
+    __shared__ uint4 smem[G * BSZ > RSZ ? G * BSZ : RSZ];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 8, wave = (threadIdx.x >> 6) & 3, hl = lane >> 5, i = lane & 31;
+    uint4 (*Bs)[4 * NS * 64] = reinterpret_cast<uint4 (*)[4 * NS * 64]>(smem + grp * BSZ);
+    const int m = blockIdx.x * 128 + wave * 32 + i, n0 = blockIdx.y * 64, cbase = blockIdx.z * NCH;
+    const bool mok = m < a.M;
+    int b = 0, oy = 0, ox = 0;
+    if (LAYER != 4) { b = m / 25; const int rem = m - b * 25; oy = rem / 5; ox = rem - oy * 5; }
+    auto loadA = [&](int c, uint4 (&r)[2][NS]) {
+#if FB_SP_ABL & 1
+        for (int s = 0; s < 2; s++) for (int p = 0; p < NS; p++) r[s][p] = make_uint4(0x3f803f80u + c, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
+        return;
+#endif
+        bool ok = mok;
+        size_t off;
+        if (LAYER == 2) {
+            const int iy = 2 * oy + (c >> 2) - 1, ix = 2 * ox + (c & 3) - 1;
+            ok = ok && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
+            off = ((size_t)b * 100 + (ok ? iy * 10 + ix : 0)) * 32 + 8 * hl;
+        } else if (LAYER == 3) {
+            const int cell = c >> 1, ky = cell / 3, kx = cell - 3 * ky, iy = oy + ky - 1, ix = ox + kx - 1;
+            ok = ok && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
+            off = ((size_t)b * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * (c & 1) + 8 * hl;
+        } else {
+            off = (size_t)(ok ? m : 0) * 1600 + (size_t)(cbase + c) * 32 + 8 * hl;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int p = 0; p < NS; p++) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4 *>(a.ain + p * a.aplane + off + 16 * s);
+                r[s][p] = v;
+            }
+    };
+    auto loadB = [&](int c, uint4 (&r)[NS]) {
+#if FB_SP_ABL & 2
+        for (int q = 0; q < NS; q++) r[q] = make_uint4(0x3f803f80u + c, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;       // LDS entry e = k8 * NS + plane
+            r[q] = a.w[((size_t)((cbase + c) * 4 + k8) * 3 + pl) * a.N + n0 + lane];
+        }
+    };
+    auto storeB = [&](int buf, const uint4 (&r)[NS]) {
+#pragma unroll
+        for (int q = 0; q < NS; q++) Bs[buf][(wave + 4 * q) * 64 + lane] = r[q];
+    };
+    f32x16 acc[2] = {{0}, {0}};
+    uint4 acur[2][NS], anxt[2][NS], bst[NS];
+    loadA(grp, acur); loadB(grp, bst); storeB(0, bst);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int c = it;                        // LDS buffer parity; the chunk itself is grp + G * it
+        if (it + 1 < NIT) { loadB(grp + G * (it + 1), bst); loadA(grp + G * (it + 1), anxt); }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                bf16x8 B[NS];
+#pragma unroll
+                for (int p = 0; p < NS; p++) B[p] = __builtin_bit_cast(bf16x8, Bs[c & 1][((2 * s + hl) * NS + p) * 64 + ct * 32 + i]);
+#define FB_SPM(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[s][pa]), B[pb], acc[ct], 0, 0, 0)
+#if FB_SP_ABL & 4
+                acc[ct][0] += __uint_as_float(acur[s][0].x ^ acur[s][NS - 1].y) * __builtin_bit_cast(float, Bs[c & 1][((2 * s + hl) * NS) * 64 + ct * 32 + i].x);
+#else
+                if (NS == 3) { FB_SPM(2, 0); FB_SPM(1, 1); FB_SPM(0, 2); FB_SPM(1, 0); FB_SPM(0, 1); }      // small terms first
+                FB_SPM(0, 0);
+#endif
+#undef FB_SPM
+            }
+        }
+        if (it + 1 < NIT) {
+            storeB((c + 1) & 1, bst);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int p = 0; p < NS; p++) acur[s][p] = anxt[s][p];
+        }
+    }
+    if (G > 1) {
+        float *red = reinterpret_cast<float *>(smem);
+        __syncthreads();                                   // every group is done with its weight buffers
+        if (grp > 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(((grp - 1) * 4 + wave) * 32 + ct * 16 + r) * 64 + lane] = acc[ct][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < G; g++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[ct][r] += red[(((g - 1) * 4 + wave) * 32 + ct * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+        const int col = n0 + ct * 32 + i;
+        const float bias = LAYER == 4 ? 0.f : a.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = blockIdx.x * 128 + wave * 32 + drow(r, lane);
+            if (mr >= a.M) continue;
+#if FB_SP_ABL & 8
+            if (acc[ct][r] != 12345.678f) continue;
+#endif
+            if (LAYER == 4) a.hfp[((size_t)blockIdx.z * a.stot + mr) * a.N + col] = acc[ct][r];
+            else {
+                uint32_t hi, mid, lo;
+                split3(fmaxf(acc[ct][r] + bias, 0.f), hi, mid, lo);
+                uint16_t *o = a.outp + (size_t)mr * 64 + col;
+                o[0] = (uint16_t)hi;
+                if (NS == 3) { o[a.oplane] = (uint16_t)mid; o[2 * a.oplane] = (uint16_t)lo; }
+            }
+        }
     }
 }
 
@@ -869,6 +1066,10 @@ struct fb_qnet {
     NetOff off;
     float *params[2], *adam_m, *adam_v, *grad, *slabs;
     uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
+    uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
+    bool wsp_stale[2];               // parameters changed since wsp was built
+    uint16_t *a1s, *a2s, *a3s;       // activation planes of that path: [3][S*3200], [3][S*1600], [3][S*1600] bf16
+    int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
@@ -906,6 +1107,10 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
+    const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)200 * 3 * fc_width) * sizeof(uint4);
+    alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
+    h->wsp_stale[0] = h->wsp_stale[1] = true; h->nsplit = 3;
+    alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a2s, S * 1600 * 6); alloc((void **)&h->a3s, S * 1600 * 6);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
     alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
@@ -923,7 +1128,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
-    void *ptrs[] = {h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+    void *ptrs[] = {h->wsp[0], h->wsp[1], h->a1s, h->a2s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -954,6 +1159,7 @@ extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *
                        h->params[which], h->n, h->off, h->FC, h->A, h->arch == FB_ARCH_DUELING, (uint32_t)seed,
                        (uint32_t)(seed >> 32));
     hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
+    h->wsp_stale[which] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -962,6 +1168,7 @@ extern "C" int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat, vo
     FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_load_params: bad argument");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[which], flat, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
     hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
+    h->wsp_stale[which] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -1012,6 +1219,7 @@ enum KernelId {
 
 struct Plan {
     Slices sl; int ns;                       // forward slices
+    int which;                               // forward-only plans: the net the single slice runs through
     bool nib;                                // states are the env's nibble state (acting path)
     uint8_t *actions; float epsilon; uint64_t seed, step;
     bool train;                              // forward only when false
@@ -1025,27 +1233,55 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
     // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
     const bool big = maxc >= 256;
+    // forward only (no activations kept for a backward) and big: the split-bf16 path
+    const bool sp = big && !p.train && p.ns == 1;
     const int t1 = (maxc * 100 + 7) / 8, t23 = (maxc * 25 + 31) / 32;
-    FB_K(K_CONV1) {
-        if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
-        else hipLaunchKernelGGL(conv1_pool_kernel<false>, dim3((t1 + 3) / 4, 1, p.ns), dim3(256), 0, st, p.sl, h->p1, h->amax);
+    const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
+    if (sp && h->wsp_stale[p.which]) {
+        const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
+        hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, p.sl.s[0].params, h->wsp[p.which], h->FC);
+        h->wsp_stale[p.which] = false;
     }
-    FB_K(K_CONV2) {
+    FB_K(K_CONV1) {
+        const dim3 g1((t1 + 3) / 4, 1, p.ns);
+        if (sp) {
+            if (p.nib) hipLaunchKernelGGL((conv1_pool_kernel<true, true>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, h->nsplit);
+            else hipLaunchKernelGGL((conv1_pool_kernel<false, true>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, h->nsplit);
+        } else if (p.nib) hipLaunchKernelGGL((conv1_pool_kernel<true, false>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, 3);
+        else hipLaunchKernelGGL((conv1_pool_kernel<false, false>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, 3);
+    }
+    const int stot = 3 * h->max_batch;
+    if (sp) {
+        const int M = maxc * 25;
+        SpArgs a2{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, h->a2s, pl2, nullptr, 0, M, 64};
+        SpArgs a3{h->a2s, pl2, h->wsp[p.which] + WSP_W3, p.sl.s[0].params + OFF_B3, h->a3s, pl2, nullptr, 0, M, 64};
+        SpArgs a4{h->a3s, pl2, h->wsp[p.which] + WSP_WF1, nullptr, nullptr, 0, h->hf, stot, maxc, h->FC};
+        const dim3 g23((M + 127) / 128, 1, 1), g4((maxc + 127) / 128, h->FC / 64, FC1_KS);
+        if (h->nsplit == 3) {
+            FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 3, SPG>), g23, dim3(256 * SPG), 0, st, a2);
+            FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 3, SPG>), g23, dim3(256 * SPG), 0, st, a3);
+            FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 3, SPG>), g4, dim3(256 * SPG), 0, st, a4);
+        } else {
+            FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 1, SPG>), g23, dim3(256 * SPG), 0, st, a2);
+            FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 1, SPG>), g23, dim3(256 * SPG), 0, st, a3);
+            FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 1, SPG>), g4, dim3(256 * SPG), 0, st, a4);
+        }
+    }
+    if (!sp) FB_K(K_CONV2) {
         if (big) hipLaunchKernelGGL(conv2_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->p1, h->h2);
         else hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
     }
-    FB_K(K_CONV3) {
+    if (!sp) FB_K(K_CONV3) {
         if (big) hipLaunchKernelGGL(conv3_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->h2, h->h3);
         else hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
     }
-    const int stot = 3 * h->max_batch;
-    FB_K(K_FC1) {
+    if (!sp) FB_K(K_FC1) {
         if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_BIG_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
         else hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
     }
     FB_K(K_HEAD) {
         HeadArgs H;
-        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
+        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = sp ? FC1_KS : big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
         H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
         H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
         H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
@@ -1082,6 +1318,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (p.apply_adam) FB_K(K_ADAM)
             hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam,
                                (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0]);
+        if (p.apply_adam && (only < 0 || only == K_ADAM)) h->wsp_stale[0] = true;
     }
 #undef FB_K
     FB_LAUNCH_CHECK();
@@ -1091,7 +1328,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
 static Plan forward_plan(fb_qnet *h, int which, const uint8_t *states, int n) {
     Plan p; memset(&p, 0, sizeof(p));
     p.sl.s[0] = Slice{h->params[which], states, 0, n, h->w1s[which]};
-    p.ns = 1;
+    p.ns = 1; p.which = which;
     return p;
 }
 
@@ -1135,6 +1372,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
     hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
                        (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0]);
+    h->wsp_stale[0] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -1143,6 +1381,7 @@ extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     FB_REQUIRE(h, "fb_qnet_sync_target: NULL handle");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[1], h->params[0], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
     FB_CHECK_HIP(hipMemcpyAsync(h->w1s[1], h->w1s[0], 3 * 8192 * 2, hipMemcpyDeviceToDevice, fb_stream(stream)));
+    h->wsp_stale[1] = true;
     return FB_OK;
 }
 

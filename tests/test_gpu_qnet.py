@@ -47,6 +47,30 @@ def test_forward_q_within_1e4(torch_cuda, oracle, dueling, B):
     assert np.array_equal(net.store_params().cpu().numpy(), p)
 
 
+@pytest.mark.parametrize("dueling,N", [(False, 256), (False, 333), (True, 1000)])
+def test_large_batch_forward_split_bf16_path(torch_cuda, oracle, dueling, N):
+    """>= 256 states, forward only: the split-bf16 path (three bf16 planes per fp32 value, six bf16 MFMAs per
+    product).  Same 1e-4 bound against the oracle, and within 2e-6 relative of the fp32-MFMA kernels that the
+    same states take when they are fed in slices of 128."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet
+    rng = np.random.default_rng(N)
+    cfg = oracle.qcfg(512, 2, dueling)
+    p = trained_like_params(oracle, cfg, seed=N)
+    net = QNet(2, 512, "dueling" if dueling else "plain", max_batch=N)
+    net.load_params(p)
+    s = rand_states(rng, N)
+    sd = torch.from_numpy(s).cuda()
+    q = net.forward(sd).cpu().numpy()
+    want = oracle.forward(p, cfg, s)
+    assert np.abs(want).max() > 0.05
+    np.testing.assert_allclose(q, want, rtol=0, atol=Q_ATOL)
+    q32 = np.concatenate([net.forward(sd[i:i + 128]).cpu().numpy() for i in range(0, N, 128)])
+    assert np.abs(q - q32).max() <= 2e-6 * np.abs(want).max()
+    # the error of both against the fp64-accumulating oracle is of the same order
+    assert np.abs(q - want).max() <= 4 * np.abs(q32 - want).max() + 1e-7
+
+
 def oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw):
     q, acts = oracle.forward(p_on, cfg, s, keep=True)
     if algo == "dqn":
