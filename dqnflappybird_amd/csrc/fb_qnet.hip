@@ -199,11 +199,8 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 // last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
 // bf16x8 operand comes out of a 256-entry LDS table with one ds_read_b128 -- no u8 -> bf16 conversion, and
 // the 25.6 KB/env currentState expansion (its own launch before) disappears.
-// SP = true (split-bf16 inference path): the pooled output is written as three bf16 planes p1s[plane][pixel][32]
-// and no argmax is kept (there is no backward).
-template <bool NIB, bool SP>
-__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax,
-                                                         uint16_t *__restrict__ p1s, size_t p1plane, int nsplit) {
+template <bool NIB>
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
     __shared__ uint4 lut[NIB ? 256 : 1];
     if (NIB) {
         const unsigned t = threadIdx.x;                       // element j = 4*px + f  <->  bit j of the byte; 255.0 = 0x437F
@@ -263,12 +260,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
         const int Pp = tile * 8 + 2 * g + hl;
         if (Pp < npool) {
             const size_t o = ((size_t)s.s_off * 100 + Pp) * 32 + j;
-            if (SP) {
-                uint32_t hi, mid, lo;
-                split3(bv, hi, mid, lo);
-                p1s[o] = (uint16_t)hi;
-                if (nsplit == 3) { p1s[p1plane + o] = (uint16_t)mid; p1s[2 * p1plane + o] = (uint16_t)lo; }
-            } else { p1[o] = bv; amax[o] = (uint8_t)best; }
+            p1[o] = bv; amax[o] = (uint8_t)best;
         }
     }
 }
@@ -453,16 +445,113 @@ __global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restric
     o[2 * N] = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
 }
 
+// conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
+// L1/L2 traffic at 1024 states); here a workgroup parks them in LDS once and its waves walk over tiles, the
+// next tile's input bytes in flight while the current one is in the MFMAs.  Operands are swapped (D = W^T x A^T):
+// a lane then holds 16 channels of ONE window position, the 2x2 pool is a max over the 4 lanes of a quad (DPP),
+// and every lane stores 4 consecutive channels of a pooled pixel as 8 bytes per plane (512 B per wave, contiguous).
+__device__ __forceinline__ float quad_max(float v) {
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));      // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+}
+
+#ifndef FB_C1_WAVES
+#define FB_C1_WAVES 3
+#endif
+template <bool NIB>
+__global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
+                                                                     size_t p1plane, int nsplit) {
+    __shared__ uint4 wl[3 * 16 * 64];
+    __shared__ uint4 lut[NIB ? 256 : 1];
+    for (int q = threadIdx.x; q < 3 * 16 * 64; q += 256) wl[q] = reinterpret_cast<const uint4 *>(s.w1s)[q];
+    if (NIB) {
+        const unsigned t = threadIdx.x;
+        uint4 e;
+        e.x = ((t >> 0) & 1u) * 0x437Fu | ((t >> 1) & 1u) * 0x437F0000u;
+        e.y = ((t >> 2) & 1u) * 0x437Fu | ((t >> 3) & 1u) * 0x437F0000u;
+        e.z = ((t >> 4) & 1u) * 0x437Fu | ((t >> 5) & 1u) * 0x437F0000u;
+        e.w = ((t >> 6) & 1u) * 0x437Fu | ((t >> 7) & 1u) * 0x437F0000u;
+        lut[t] = e;
+    }
+    __syncthreads();
+    typedef typename std::conditional<NIB, unsigned, uint2>::type Raw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31, pp = j >> 2, pos = j & 3;
+    const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = gridDim.x * 4;
+    float b4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) b4[e] = s.params[OFF_B1 + 8 * pos + 4 * hl + e];
+    auto fetch = [&](int tile, Raw (&raw)[16]) {
+        const int P = tile * 8 + pp, b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
+        const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+#pragma unroll
+        for (int ky = 0; ky < 8; ky++) {
+            const int iy = oy * 4 + ky - 2;
+            const bool rowok = P < npool && iy >= 0 && iy < 80;
+            const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * (NIB ? 1 : 8) / 2;
+#pragma unroll
+            for (int kq = 0; kq < 2; kq++) {
+                const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;
+                const bool ok = rowok && ix >= 0 && ix < 80;
+                // padding taps read the zero page (LUT entry 0 = zeros): no branch, so no vmcnt(0) at a join
+                if constexpr (NIB) raw[ky * 2 + kq] = *(ok ? row + (ix >> 1) : zeros);
+                else raw[ky * 2 + kq] = *reinterpret_cast<const uint2 *>(ok ? row + (size_t)ix * 4 : zeros);
+            }
+        }
+    };
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    Raw cur[16], nxt[16];
+    fetch(tile, cur);
+    for (; tile < ntiles; tile += stride) {
+        if (tile + stride < ntiles) fetch(tile + stride, nxt);
+        int z;                                   // opaque 0: keeps the 48 weight fragments in LDS (re-read per tile)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));      // instead of hoisted into 192 registers at one wave per SIMD
+        const uint4 *wlz = wl + z;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            bf16x8 A;
+            if constexpr (NIB) A = __builtin_bit_cast(bf16x8, lut[cur[c]]);
+            else A = u8x8_to_bf16(cur[c]);
+#pragma unroll
+            for (int part = 0; part < 3; part++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), A, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = quad_max(acc[r]);
+        const int Pp = tile * 8 + pp;
+        uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float v = pos == 0 ? acc[e] : pos == 1 ? acc[4 + e] : pos == 2 ? acc[8 + e] : acc[12 + e];
+            split3(fmaxf(v + b4[e], 0.f), hi[e], mid[e], lo[e]);
+        }
+        if (Pp < npool) {
+            uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 8 * pos + 4 * hl;
+            *reinterpret_cast<uint2 *>(o) = make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16);
+            if (nsplit == 3) {
+                *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16);
+                *reinterpret_cast<uint2 *>(o + 2 * p1plane) = make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) cur[q] = nxt[q];
+    }
+}
+
 #ifndef FB_SP_ABL
 #define FB_SP_ABL 0
 #endif
 #ifndef FB_SPG
-#define FB_SPG 2
+#define FB_SPG 1
 #endif
 constexpr int SPG = FB_SPG;
 
 struct SpArgs {
     const uint16_t *ain; size_t aplane;      // input planes [3][rows][C] bf16
+    const uint16_t *zeros;                   // >= 64 B of zeros: where the SAME-padding taps and the rows past M load from
     const uint4 *w;                          // this layer's split weights
     const float *bias;
     uint16_t *outp; size_t oplane;           // LAYER 2, 3: relu(acc + bias) as planes [3][M][64]
@@ -484,7 +573,7 @@ __global__ __launch_bounds__(256 * G) void sp_gemm_kernel(SpArgs a) {
     static_assert(NCH % G == 0, "chunks must divide over the wave groups");
     constexpr int BSZ = 2 * 4 * NS * 64, RSZ = (G - 1) * 4 * 32 * 64 / 4;        // uint4 units
     __shared__ uint4 smem[G * BSZ > RSZ ? G * BSZ : RSZ];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 8, wave = (threadIdx.x >> 6) & 3, hl = lane >> 5, i = lane & 31;
+    const int lane = threadIdx.x & 63, grp = G == 1 ? 0 : threadIdx.x >> 8, wave = (threadIdx.x >> 6) & 3, hl = lane >> 5, i = lane & 31;
     uint4 (*Bs)[4 * NS * 64] = reinterpret_cast<uint4 (*)[4 * NS * 64]>(smem + grp * BSZ);
     const int m = blockIdx.x * 128 + wave * 32 + i, n0 = blockIdx.y * 64, cbase = blockIdx.z * NCH;
     const bool mok = m < a.M;
@@ -508,14 +597,14 @@ __global__ __launch_bounds__(256 * G) void sp_gemm_kernel(SpArgs a) {
         } else {
             off = (size_t)(ok ? m : 0) * 1600 + (size_t)(cbase + c) * 32 + 8 * hl;
         }
+        // no branch around a load (hipcc would wait vmcnt(0) at every join and drain the prefetch): padding lanes
+        // read the zero page instead
+        const uint16_t *src = ok ? a.ain + off : a.zeros;
+        const size_t pstride = ok ? a.aplane : 0;
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
-            for (int p = 0; p < NS; p++) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint4 *>(a.ain + p * a.aplane + off + 16 * s);
-                r[s][p] = v;
-            }
+            for (int p = 0; p < NS; p++) r[s][p] = *reinterpret_cast<const uint4 *>(src + p * pstride + 16 * s);
     };
     auto loadB = [&](int c, uint4 (&r)[NS]) {
 #if FB_SP_ABL & 2
@@ -605,6 +694,189 @@ __global__ __launch_bounds__(256 * G) void sp_gemm_kernel(SpArgs a) {
             }
         }
     }
+}
+
+// conv2 + conv3 of that path in ONE kernel, five states per workgroup (125 of its 128 MFMA rows).  A 10x10x32
+// conv2 input is 19 KB as three bf16 planes: the five of them are copied into LDS once, in full cache lines,
+// and both convolutions gather their im2col fragments from LDS (ds_read_b128) -- the 4x (conv2) and 9x (conv3)
+// re-reads of the input and the fragment-shaped 16-byte global loads that bound sp_gemm_kernel<2|3> are gone,
+// and conv2's output never leaves the CU.  Only the weights stream: 34 chunks of 32 k (16 conv2 taps, 18 conv3
+// half taps) through a 3-slot LDS ring, fetched two chunks ahead.  Operands are swapped (D = W^T x A^T) so that a
+// lane owns 4 consecutive channels of one pixel per register quad: 8-byte plane stores instead of 2-byte ones.
+// LDS images are piece-rotated / XOR-swizzled so that the 16-lane groups of a ds_read_b128 spread over the banks.
+struct C23Args {
+    const uint16_t *p1s; size_t pl1;         // conv2 input planes [3][n*100][32]
+    const uint4 *w;                          // split weights: conv2 chunks 0..15, conv3 chunks 16..33 (wsp + WSP_W2)
+    const float *b2, *b3;
+    uint16_t *a3s; size_t pl3;               // conv3 output planes [3][n*25][64]
+    int n;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
+    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NS * IN_P, RING = ZOFF + 16, RSZ = 4 * NS * 64;   // uint4 units
+    __shared__ uint4 smem[RING + 3 * RSZ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
+    const int s0 = blockIdx.x * 5, ml = wave * 32 + j;
+    const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
+    const bool rowok = ml < 125;
+    int nloc = a.n - s0; if (nloc > 5) nloc = 5;
+    // weight staging registers: named members, no arrays (hipcc otherwise parks them in LDS / scratch)
+    struct BSt { uint4 v0, v1, v2; };
+    auto srcB = [&](int cc, int q) {
+        const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;
+        return a.w + (size_t)cc * 768 + (k8 * 3 + pl) * 64 + lane;
+    };
+#ifndef FB_C23_ABL
+#define FB_C23_ABL 0
+#endif
+    auto loadB = [&](int cc) {               // by value throughout: a reference into a lambda defeats SROA (staging lands in LDS)
+        BSt r;
+#if FB_C23_ABL & 2
+        r.v0 = make_uint4(0x3f803f80u + cc, 0x3f803f80u, lane, wave); r.v1 = r.v0; r.v2 = r.v0; return r;
+#endif
+        r.v0 = *srcB(cc, 0);
+        if (NS == 3) { r.v1 = *srcB(cc, 1); r.v2 = *srcB(cc, 2); } else { r.v1 = r.v0; r.v2 = r.v0; }
+        return r;
+    };
+    auto storeB = [&](int slot, const BSt r) {
+        uint4 *d = smem + RING + slot * RSZ + wave * 64 + lane;
+        d[0] = r.v0;
+        if (NS == 3) { d[256] = r.v1; d[512] = r.v2; }
+    };
+    BSt bstA = loadB(0), bstB = loadB(1);
+    {   // the five input images, plane by plane; piece q of pixel pix lands on piece (q + (pix >> 2)) & 3
+        uint4 t[NS][8];
+#pragma unroll
+        for (int p = 0; p < NS; p++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int q = threadIdx.x + 256 * r;
+                const bool ok = q < nloc * 400;
+                t[p][r] = make_uint4(0u, 0u, 0u, 0u);
+#if !(FB_C23_ABL & 4)
+                if (ok) t[p][r] = reinterpret_cast<const uint4 *>(a.p1s + p * a.pl1 + (size_t)s0 * 3200)[q];
+#endif
+            }
+#pragma unroll
+        for (int p = 0; p < NS; p++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int q = threadIdx.x + 256 * r, pix = q >> 2;
+                if (q < IN_P) smem[p * IN_P + pix * 4 + ((q + (pix >> 2)) & 3)] = t[p][r];
+            }
+        if (threadIdx.x < 16) smem[ZOFF + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // Software pipeline (everything by value -- a reference into a lambda defeats SROA): while the 24 MFMAs of chunk
+    // cc run on fragments already in registers, the fragments of chunk cc + 1 are read from LDS into a second
+    // register set, the staged weights of chunk cc + 2 go into ring slot (cc + 2) % 3 and the global loads of chunk
+    // cc + 4 are issued; one barrier per chunk.
+    struct Fr { uint4 A[2][NS]; uint4 W[2][2][NS]; };
+    auto readW = [&](int cc, Fr f) {
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int p = 0; p < NS; p++) f.W[s][ct][p] = smem[RING + (cc % 3) * RSZ + ((2 * s + hl) * NS + p) * 64 + ct * 32 + j];
+        return f;
+    };
+    auto readA = [&](auto aidx, Fr f) {          // aidx(s, p) -> LDS index of this lane's activation fragment
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int p = 0; p < NS; p++) f.A[s][p] = smem[aidx(s, p)];
+        return f;
+    };
+    f32x16 acc[2] = {{0}, {0}};
+    auto compute = [&](const Fr f) {
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+#define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.W[s][ct][pb]), __builtin_bit_cast(bf16x8, f.A[s][pa]), acc[ct], 0, 0, 0)
+#if FB_C23_ABL & 1
+                acc[ct][0] += __uint_as_float(f.W[s][ct][0].x ^ f.W[s][ct][NS - 1].y) * __uint_as_float(f.A[s][0].x ^ f.A[s][NS - 1].z);
+#else
+                if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }
+                FB_M(0, 0);
+#endif
+#undef FB_M
+            }
+    };
+    auto a2 = [&](int c) {                       // conv2 chunk c = tap (ky, kx), 32 channels
+        const int iy = 2 * oy + (c >> 2) - 1, ix = 2 * ox + (c & 3) - 1;
+        const bool ok = rowok && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
+        const int pix = bl * 100 + iy * 10 + ix, hl_ = hl;
+        return [=](int s, int p) { return ok ? p * IN_P + pix * 4 + ((2 * s + hl_ + (pix >> 2)) & 3) : ZOFF; };
+    };
+    auto a3 = [&](int c) {                       // conv3 chunk c = half a tap (ky, kx), channels 32 * (c & 1) ..
+        const int cell = c >> 1, ky = cell / 3, kx = cell - 3 * ky, iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool ok = rowok && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
+        const int pix = bl * 25 + iy * 5 + ix, hl_ = hl;
+        return [=](int s, int p) { return ok ? p * C2_P + pix * 8 + ((4 * (c & 1) + 2 * s + hl_) ^ ((pix >> 1) & 7)) : ZOFF; };
+    };
+    storeB(0, bstA); bstA = loadB(2);
+    __syncthreads();
+    storeB(1, bstB); bstB = loadB(3);
+    Fr cur = {};
+    cur = readA(a2(0), readW(0, cur));
+    __syncthreads();
+#define FB_STEP(cc, ST, AIDX_NEXT, HAVE_A)                                                                        \
+    {                                                                                                                  \
+        Fr nx = cur;                                                                                                   \
+        if ((cc) + 1 < 34 && !(FB_C23_ABL & 32)) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }  \
+        __builtin_amdgcn_sched_barrier(0);      /* keep the prefetch reads ahead of the MFMAs (hipcc sinks them to their uses) */ \
+        compute(cur);                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if ((cc) + 2 < 34 && !(FB_C23_ABL & 64)) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); } \
+        if (!(FB_C23_ABL & 16)) __syncthreads();                                                                       \
+        cur = nx;                                                                                                      \
+    }
+    // relu(acc + bias) of this lane's 32 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half)
+    auto epilogue = [&](const float *__restrict__ bias, auto put) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + ct * 32 + 8 * g + 4 * hl);
+                uint32_t hi[4], mid[4], lo[4];
+                split3(fmaxf(acc[ct][4 * g] + bv.x, 0.f), hi[0], mid[0], lo[0]);
+                split3(fmaxf(acc[ct][4 * g + 1] + bv.y, 0.f), hi[1], mid[1], lo[1]);
+                split3(fmaxf(acc[ct][4 * g + 2] + bv.z, 0.f), hi[2], mid[2], lo[2]);
+                split3(fmaxf(acc[ct][4 * g + 3] + bv.w, 0.f), hi[3], mid[3], lo[3]);
+                put(0, ct * 4 + g, make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16));
+                if (NS == 3) {
+                    put(1, ct * 4 + g, make_uint2(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16));
+                    put(2, ct * 4 + g, make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16));
+                }
+                acc[ct][4 * g] = 0.f; acc[ct][4 * g + 1] = 0.f; acc[ct][4 * g + 2] = 0.f; acc[ct][4 * g + 3] = 0.f;
+            }
+    };
+    // ---- conv2
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        FB_STEP(c, bstA, a2(c + 1), true);
+        FB_STEP(c + 1, bstB, a2(c + 2), c + 2 < 16);       // chunk 16's activations do not exist yet
+    }
+    // its output pixel ml (= bl * 25 + oy * 5 + ox), 64 channels = 8 pieces, piece q on q ^ ((ml >> 1) & 7); aliases the input
+    // images, which every wave has finished reading (barrier at the end of chunk 15)
+    epilogue(a.b2, [&](int p, int piece, uint2 v) {
+        if (rowok) reinterpret_cast<uint2 *>(smem + p * C2_P + ml * 8 + (piece ^ ((ml >> 1) & 7)))[hl] = v;
+    });
+    __syncthreads();
+    // ---- conv3 (its first weight fragments are already in `cur`)
+    cur = readA(a3(0), cur);
+#pragma unroll
+    for (int c = 0; c < 18; c += 2) {
+        FB_STEP(16 + c, bstA, a3(c + 1), true);
+        FB_STEP(16 + c + 1, bstB, a3(c + 2), c + 2 < 18);
+    }
+#undef FB_STEP
+    epilogue(a.b3, [&](int p, int piece, uint2 v) {
+        if (rowok && bl < nloc && !((FB_C23_ABL & 8) && v.x != 0x12345u))
+            *reinterpret_cast<uint2 *>(a.a3s + p * a.pl3 + ((size_t)s0 * 25 + ml) * 64 + piece * 8 + 4 * hl) = v;
+    });
 }
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
@@ -1068,6 +1340,7 @@ struct fb_qnet {
     uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
     uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
     bool wsp_stale[2];               // parameters changed since wsp was built
+    uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
     uint16_t *a1s, *a2s, *a3s;       // activation planes of that path: [3][S*3200], [3][S*1600], [3][S*1600] bf16
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
     AdamDev *adam;
@@ -1110,6 +1383,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)200 * 3 * fc_width) * sizeof(uint4);
     alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
     h->wsp_stale[0] = h->wsp_stale[1] = true; h->nsplit = 3;
+    alloc((void **)&h->zeros, 256);
     alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a2s, S * 1600 * 6); alloc((void **)&h->a3s, S * 1600 * 6);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
@@ -1128,7 +1402,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
-    void *ptrs[] = {h->wsp[0], h->wsp[1], h->a1s, h->a2s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+    void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a2s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -1244,26 +1518,47 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
+#ifdef FB_CONV1_OLD
+        if (false) {
+#else
         if (sp) {
-            if (p.nib) hipLaunchKernelGGL((conv1_pool_kernel<true, true>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, h->nsplit);
-            else hipLaunchKernelGGL((conv1_pool_kernel<false, true>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, h->nsplit);
-        } else if (p.nib) hipLaunchKernelGGL((conv1_pool_kernel<true, false>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, 3);
-        else hipLaunchKernelGGL((conv1_pool_kernel<false, false>), g1, dim3(256), 0, st, p.sl, h->p1, h->amax, h->a1s, pl1, 3);
+#endif
+            // persistent: every wave takes `rounds` tiles, about 3 workgroups per CU
+            const int rounds = (t1 + 3071) / 3072, gsp = (t1 + 4 * rounds - 1) / (4 * rounds);
+            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit);
+            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit);
+        } else if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
+        else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
     const int stot = 3 * h->max_batch;
     if (sp) {
         const int M = maxc * 25;
-        SpArgs a2{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, h->a2s, pl2, nullptr, 0, M, 64};
-        SpArgs a3{h->a2s, pl2, h->wsp[p.which] + WSP_W3, p.sl.s[0].params + OFF_B3, h->a3s, pl2, nullptr, 0, M, 64};
-        SpArgs a4{h->a3s, pl2, h->wsp[p.which] + WSP_WF1, nullptr, nullptr, 0, h->hf, stot, maxc, h->FC};
+        SpArgs a2{h->a1s, pl1, h->zeros, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, h->a2s, pl2, nullptr, 0, M, 64};
+        SpArgs a3{h->a2s, pl2, h->zeros, h->wsp[p.which] + WSP_W3, p.sl.s[0].params + OFF_B3, h->a3s, pl2, nullptr, 0, M, 64};
+        SpArgs a4{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, nullptr, nullptr, 0, h->hf, stot, maxc, h->FC};
         const dim3 g23((M + 127) / 128, 1, 1), g4((maxc + 127) / 128, h->FC / 64, FC1_KS);
+        C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc};
+        const dim3 gc((maxc + 4) / 5);
+#ifdef FB_SP_UNFUSED
+        (void)c23; (void)gc;
+#else
+        (void)a2; (void)a3; (void)g23;
+#endif
         if (h->nsplit == 3) {
+#ifdef FB_SP_UNFUSED
             FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 3, SPG>), g23, dim3(256 * SPG), 0, st, a2);
             FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 3, SPG>), g23, dim3(256 * SPG), 0, st, a3);
+#else
+            FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
+#endif
             FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 3, SPG>), g4, dim3(256 * SPG), 0, st, a4);
         } else {
+#ifdef FB_SP_UNFUSED
             FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 1, SPG>), g23, dim3(256 * SPG), 0, st, a2);
             FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 1, SPG>), g23, dim3(256 * SPG), 0, st, a3);
+#else
+            FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(256), 0, st, c23);
+#endif
             FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 1, SPG>), g4, dim3(256 * SPG), 0, st, a4);
         }
     }
