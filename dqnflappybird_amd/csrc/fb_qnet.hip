@@ -164,6 +164,20 @@ __device__ __forceinline__ void split3(float x, uint32_t &hi, uint32_t &mid, uin
     lo = f32_to_bf16_rn(r1 - __uint_as_float(mid << 16));
 }
 
+// the same split for two values at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even):
+// each output word packs the two bf16 (x0 in the low half)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3x2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    const f32x2 x = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h); mid = __builtin_bit_cast(uint32_t, m); lo = __builtin_bit_cast(uint32_t, l);
+}
+
 __device__ __forceinline__ void split_w1(const float w, int idx /* flat index in W_conv1[8][8][4][32] */, uint16_t *__restrict__ w1s) {
     const int co = idx & 31, f = (idx >> 5) & 3, kx = (idx >> 7) & 7, ky = idx >> 10;
     const int kq = kx >> 2, h = (kx >> 1) & 1, j = (kx & 1) * 4 + f;
@@ -436,13 +450,14 @@ __global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restric
     else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
     else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
     const int k8 = id / N, col = id - k8 * N;
-    uint32_t hi[8], mid[8], lo[8];
+    uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) split3(W[(size_t)(k8 * 8 + e) * N + col], hi[e], mid[e], lo[e]);
+    for (int e = 0; e < 4; e++)
+        split3x2(W[(size_t)(k8 * 8 + 2 * e) * N + col], W[(size_t)(k8 * 8 + 2 * e + 1) * N + col], hi[e], mid[e], lo[e]);
     uint4 *o = out + (size_t)k8 * 3 * N + col;
-    o[0] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[4] | hi[5] << 16, hi[6] | hi[7] << 16);
-    o[N] = make_uint4(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16, mid[4] | mid[5] << 16, mid[6] | mid[7] << 16);
-    o[2 * N] = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
+    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o[N] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    o[2 * N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
@@ -457,6 +472,9 @@ __device__ __forceinline__ float quad_max(float v) {
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
 }
 
+#ifndef FB_C1_ABL
+#define FB_C1_ABL 0
+#endif
 #ifndef FB_C1_WAVES
 #define FB_C1_WAVES 3
 #endif
@@ -505,7 +523,9 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     Raw cur[16], nxt[16];
     fetch(tile, cur);
     for (; tile < ntiles; tile += stride) {
+#if !(FB_C1_ABL & 4)
         if (tile + stride < ntiles) fetch(tile + stride, nxt);
+#endif
         int z;                                   // opaque 0: keeps the 48 weight fragments in LDS (re-read per tile)
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));      // instead of hoisted into 192 registers at one wave per SIMD
         const uint4 *wlz = wl + z;
@@ -513,27 +533,37 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             bf16x8 A;
+#if FB_C1_ABL & 2
+            if constexpr (NIB) A = __builtin_bit_cast(bf16x8, make_uint4(cur[c], 0x437F0000u, 0x437Fu, 0u));
+#else
             if constexpr (NIB) A = __builtin_bit_cast(bf16x8, lut[cur[c]]);
+#endif
             else A = u8x8_to_bf16(cur[c]);
 #pragma unroll
             for (int part = 0; part < 3; part++)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), A, acc, 0, 0, 0);
         }
+#if FB_C1_ABL & 1
+        if (acc[0] != 1234.5f) continue;
+#endif
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = quad_max(acc[r]);
         const int Pp = tile * 8 + pp;
-        uint32_t hi[4], mid[4], lo[4];
+        float o4[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const float v = pos == 0 ? acc[e] : pos == 1 ? acc[4 + e] : pos == 2 ? acc[8 + e] : acc[12 + e];
-            split3(fmaxf(v + b4[e], 0.f), hi[e], mid[e], lo[e]);
+            o4[e] = fmaxf(v + b4[e], 0.f);
         }
+        uint32_t hi[2], mid[2], lo[2];
+        split3x2(o4[0], o4[1], hi[0], mid[0], lo[0]);
+        split3x2(o4[2], o4[3], hi[1], mid[1], lo[1]);
         if (Pp < npool) {
             uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 8 * pos + 4 * hl;
-            *reinterpret_cast<uint2 *>(o) = make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16);
+            *reinterpret_cast<uint2 *>(o) = make_uint2(hi[0], hi[1]);
             if (nsplit == 3) {
-                *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16);
-                *reinterpret_cast<uint2 *>(o + 2 * p1plane) = make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);
+                *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(mid[0], mid[1]);
+                *reinterpret_cast<uint2 *>(o + 2 * p1plane) = make_uint2(lo[0], lo[1]);
             }
         }
 #pragma unroll
@@ -541,165 +571,10 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     }
 }
 
-#ifndef FB_SP_ABL
-#define FB_SP_ABL 0
-#endif
-#ifndef FB_SPG
-#define FB_SPG 1
-#endif
-constexpr int SPG = FB_SPG;
-
-struct SpArgs {
-    const uint16_t *ain; size_t aplane;      // input planes [3][rows][C] bf16
-    const uint16_t *zeros;                   // >= 64 B of zeros: where the SAME-padding taps and the rows past M load from
-    const uint4 *w;                          // this layer's split weights
-    const float *bias;
-    uint16_t *outp; size_t oplane;           // LAYER 2, 3: relu(acc + bias) as planes [3][M][64]
-    float *hfp; int stot;                    // LAYER 4: fp32 partial sums hfp[ks][sample][N]
-    int M, N;
-};
-
-// One workgroup = 128 output rows x 64 columns, 4 waves x (32 rows x 2 column tiles); K in chunks of 32:
-// the weight chunk (4 k-octets x NS planes x 64 columns x 16 B) goes global -> registers -> LDS (two buffers, one
-// barrier per chunk) and is shared by the four waves; the activation fragments (an im2col gather of 16-byte
-// channel runs) go straight to registers one chunk ahead.
-// LAYER 2: conv2 4x4x32->64 stride 2 (16 chunks = taps); LAYER 3: conv3 3x3x64->64 (18 chunks = half taps);
-// LAYER 4: fc1, K = 1600 = FC1_KS slices x 10 chunks, partial sums like fc1_kernel.
-// G groups of 4 waves share the K loop (group g takes chunks g, g + G, ...) so that every SIMD has G waves to
-// hide the operand latency behind; their accumulators meet in LDS at the end, summed in group order.
-template <int LAYER, int NS, int G>
-__global__ __launch_bounds__(256 * G) void sp_gemm_kernel(SpArgs a) {
-    constexpr int NCH = LAYER == 2 ? 16 : LAYER == 3 ? 18 : 10, NIT = NCH / G;
-    static_assert(NCH % G == 0, "chunks must divide over the wave groups");
-    constexpr int BSZ = 2 * 4 * NS * 64, RSZ = (G - 1) * 4 * 32 * 64 / 4;        // uint4 units
-    __shared__ uint4 smem[G * BSZ > RSZ ? G * BSZ : RSZ];
-    const int lane = threadIdx.x & 63, grp = G == 1 ? 0 : threadIdx.x >> 8, wave = (threadIdx.x >> 6) & 3, hl = lane >> 5, i = lane & 31;
-    uint4 (*Bs)[4 * NS * 64] = reinterpret_cast<uint4 (*)[4 * NS * 64]>(smem + grp * BSZ);
-    const int m = blockIdx.x * 128 + wave * 32 + i, n0 = blockIdx.y * 64, cbase = blockIdx.z * NCH;
-    const bool mok = m < a.M;
-    int b = 0, oy = 0, ox = 0;
-    if (LAYER != 4) { b = m / 25; const int rem = m - b * 25; oy = rem / 5; ox = rem - oy * 5; }
-    auto loadA = [&](int c, uint4 (&r)[2][NS]) {
-#if FB_SP_ABL & 1
-        for (int s = 0; s < 2; s++) for (int p = 0; p < NS; p++) r[s][p] = make_uint4(0x3f803f80u + c, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
-        return;
-#endif
-        bool ok = mok;
-        size_t off;
-        if (LAYER == 2) {
-            const int iy = 2 * oy + (c >> 2) - 1, ix = 2 * ox + (c & 3) - 1;
-            ok = ok && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
-            off = ((size_t)b * 100 + (ok ? iy * 10 + ix : 0)) * 32 + 8 * hl;
-        } else if (LAYER == 3) {
-            const int cell = c >> 1, ky = cell / 3, kx = cell - 3 * ky, iy = oy + ky - 1, ix = ox + kx - 1;
-            ok = ok && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
-            off = ((size_t)b * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * (c & 1) + 8 * hl;
-        } else {
-            off = (size_t)(ok ? m : 0) * 1600 + (size_t)(cbase + c) * 32 + 8 * hl;
-        }
-        // no branch around a load (hipcc would wait vmcnt(0) at every join and drain the prefetch): padding lanes
-        // read the zero page instead
-        const uint16_t *src = ok ? a.ain + off : a.zeros;
-        const size_t pstride = ok ? a.aplane : 0;
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int p = 0; p < NS; p++) r[s][p] = *reinterpret_cast<const uint4 *>(src + p * pstride + 16 * s);
-    };
-    auto loadB = [&](int c, uint4 (&r)[NS]) {
-#if FB_SP_ABL & 2
-        for (int q = 0; q < NS; q++) r[q] = make_uint4(0x3f803f80u + c, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
-        return;
-#endif
-#pragma unroll
-        for (int q = 0; q < NS; q++) {
-            const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;       // LDS entry e = k8 * NS + plane
-            r[q] = a.w[((size_t)((cbase + c) * 4 + k8) * 3 + pl) * a.N + n0 + lane];
-        }
-    };
-    auto storeB = [&](int buf, const uint4 (&r)[NS]) {
-#pragma unroll
-        for (int q = 0; q < NS; q++) Bs[buf][(wave + 4 * q) * 64 + lane] = r[q];
-    };
-    f32x16 acc[2] = {{0}, {0}};
-    uint4 acur[2][NS], anxt[2][NS], bst[NS];
-    loadA(grp, acur); loadB(grp, bst); storeB(0, bst);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int c = it;                        // LDS buffer parity; the chunk itself is grp + G * it
-        if (it + 1 < NIT) { loadB(grp + G * (it + 1), bst); loadA(grp + G * (it + 1), anxt); }
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ct++) {
-                bf16x8 B[NS];
-#pragma unroll
-                for (int p = 0; p < NS; p++) B[p] = __builtin_bit_cast(bf16x8, Bs[c & 1][((2 * s + hl) * NS + p) * 64 + ct * 32 + i]);
-#define FB_SPM(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[s][pa]), B[pb], acc[ct], 0, 0, 0)
-#if FB_SP_ABL & 4
-                acc[ct][0] += __uint_as_float(acur[s][0].x ^ acur[s][NS - 1].y) * __builtin_bit_cast(float, Bs[c & 1][((2 * s + hl) * NS) * 64 + ct * 32 + i].x);
-#else
-                if (NS == 3) { FB_SPM(2, 0); FB_SPM(1, 1); FB_SPM(0, 2); FB_SPM(1, 0); FB_SPM(0, 1); }      // small terms first
-                FB_SPM(0, 0);
-#endif
-#undef FB_SPM
-            }
-        }
-        if (it + 1 < NIT) {
-            storeB((c + 1) & 1, bst);
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-#pragma unroll
-                for (int p = 0; p < NS; p++) acur[s][p] = anxt[s][p];
-        }
-    }
-    if (G > 1) {
-        float *red = reinterpret_cast<float *>(smem);
-        __syncthreads();                                   // every group is done with its weight buffers
-        if (grp > 0) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) red[(((grp - 1) * 4 + wave) * 32 + ct * 16 + r) * 64 + lane] = acc[ct][r];
-        }
-        __syncthreads();
-        if (grp > 0) return;
-#pragma unroll
-        for (int g = 1; g < G; g++)
-#pragma unroll
-            for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[ct][r] += red[(((g - 1) * 4 + wave) * 32 + ct * 16 + r) * 64 + lane];
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-        const int col = n0 + ct * 32 + i;
-        const float bias = LAYER == 4 ? 0.f : a.bias[col];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = blockIdx.x * 128 + wave * 32 + drow(r, lane);
-            if (mr >= a.M) continue;
-#if FB_SP_ABL & 8
-            if (acc[ct][r] != 12345.678f) continue;
-#endif
-            if (LAYER == 4) a.hfp[((size_t)blockIdx.z * a.stot + mr) * a.N + col] = acc[ct][r];
-            else {
-                uint32_t hi, mid, lo;
-                split3(fmaxf(acc[ct][r] + bias, 0.f), hi, mid, lo);
-                uint16_t *o = a.outp + (size_t)mr * 64 + col;
-                o[0] = (uint16_t)hi;
-                if (NS == 3) { o[a.oplane] = (uint16_t)mid; o[2 * a.oplane] = (uint16_t)lo; }
-            }
-        }
-    }
-}
-
 // conv2 + conv3 of that path in ONE kernel, five states per workgroup (125 of its 128 MFMA rows).  A 10x10x32
 // conv2 input is 19 KB as three bf16 planes: the five of them are copied into LDS once, in full cache lines,
 // and both convolutions gather their im2col fragments from LDS (ds_read_b128) -- the 4x (conv2) and 9x (conv3)
-// re-reads of the input and the fragment-shaped 16-byte global loads that bound sp_gemm_kernel<2|3> are gone,
+// re-reads of the input and the fragment-shaped 16-byte global loads (64 cache lines per wave instruction) are gone,
 // and conv2's output never leaves the CU.  Only the weights stream: 34 chunks of 32 k (16 conv2 taps, 18 conv3
 // half taps) through a 3-slot LDS ring, fetched two chunks ahead.  Operands are swapped (D = W^T x A^T) so that a
 // lane owns 4 consecutive channels of one pixel per register quad: 8-byte plane stores instead of 2-byte ones.
@@ -727,14 +602,8 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
         const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;
         return a.w + (size_t)cc * 768 + (k8 * 3 + pl) * 64 + lane;
     };
-#ifndef FB_C23_ABL
-#define FB_C23_ABL 0
-#endif
     auto loadB = [&](int cc) {               // by value throughout: a reference into a lambda defeats SROA (staging lands in LDS)
         BSt r;
-#if FB_C23_ABL & 2
-        r.v0 = make_uint4(0x3f803f80u + cc, 0x3f803f80u, lane, wave); r.v1 = r.v0; r.v2 = r.v0; return r;
-#endif
         r.v0 = *srcB(cc, 0);
         if (NS == 3) { r.v1 = *srcB(cc, 1); r.v2 = *srcB(cc, 2); } else { r.v1 = r.v0; r.v2 = r.v0; }
         return r;
@@ -754,9 +623,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
                 const int q = threadIdx.x + 256 * r;
                 const bool ok = q < nloc * 400;
                 t[p][r] = make_uint4(0u, 0u, 0u, 0u);
-#if !(FB_C23_ABL & 4)
                 if (ok) t[p][r] = reinterpret_cast<const uint4 *>(a.p1s + p * a.pl1 + (size_t)s0 * 3200)[q];
-#endif
             }
 #pragma unroll
         for (int p = 0; p < NS; p++)
@@ -795,12 +662,8 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
 #define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.W[s][ct][pb]), __builtin_bit_cast(bf16x8, f.A[s][pa]), acc[ct], 0, 0, 0)
-#if FB_C23_ABL & 1
-                acc[ct][0] += __uint_as_float(f.W[s][ct][0].x ^ f.W[s][ct][NS - 1].y) * __uint_as_float(f.A[s][0].x ^ f.A[s][NS - 1].z);
-#else
-                if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }
+                if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }      // small terms first
                 FB_M(0, 0);
-#endif
 #undef FB_M
             }
     };
@@ -825,12 +688,12 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #define FB_STEP(cc, ST, AIDX_NEXT, HAVE_A)                                                                        \
     {                                                                                                                  \
         Fr nx = cur;                                                                                                   \
-        if ((cc) + 1 < 34 && !(FB_C23_ABL & 32)) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }  \
+        if ((cc) + 1 < 34) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }                        \
         __builtin_amdgcn_sched_barrier(0);      /* keep the prefetch reads ahead of the MFMAs (hipcc sinks them to their uses) */ \
         compute(cur);                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if ((cc) + 2 < 34 && !(FB_C23_ABL & 64)) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); } \
-        if (!(FB_C23_ABL & 16)) __syncthreads();                                                                       \
+        if ((cc) + 2 < 34) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); }                    \
+        __syncthreads();                                                                                               \
         cur = nx;                                                                                                      \
     }
     // relu(acc + bias) of this lane's 32 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half)
@@ -840,16 +703,11 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const float4 bv = *reinterpret_cast<const float4 *>(bias + ct * 32 + 8 * g + 4 * hl);
-                uint32_t hi[4], mid[4], lo[4];
-                split3(fmaxf(acc[ct][4 * g] + bv.x, 0.f), hi[0], mid[0], lo[0]);
-                split3(fmaxf(acc[ct][4 * g + 1] + bv.y, 0.f), hi[1], mid[1], lo[1]);
-                split3(fmaxf(acc[ct][4 * g + 2] + bv.z, 0.f), hi[2], mid[2], lo[2]);
-                split3(fmaxf(acc[ct][4 * g + 3] + bv.w, 0.f), hi[3], mid[3], lo[3]);
-                put(0, ct * 4 + g, make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16));
-                if (NS == 3) {
-                    put(1, ct * 4 + g, make_uint2(mid[0] | mid[1] << 16, mid[2] | mid[3] << 16));
-                    put(2, ct * 4 + g, make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16));
-                }
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split3x2(fmaxf(acc[ct][4 * g] + bv.x, 0.f), fmaxf(acc[ct][4 * g + 1] + bv.y, 0.f), h0, m0, l0);
+                split3x2(fmaxf(acc[ct][4 * g + 2] + bv.z, 0.f), fmaxf(acc[ct][4 * g + 3] + bv.w, 0.f), h1, m1, l1);
+                put(0, ct * 4 + g, make_uint2(h0, h1));
+                if (NS == 3) { put(1, ct * 4 + g, make_uint2(m0, m1)); put(2, ct * 4 + g, make_uint2(l0, l1)); }
                 acc[ct][4 * g] = 0.f; acc[ct][4 * g + 1] = 0.f; acc[ct][4 * g + 2] = 0.f; acc[ct][4 * g + 3] = 0.f;
             }
     };
@@ -874,9 +732,121 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     }
 #undef FB_STEP
     epilogue(a.b3, [&](int p, int piece, uint2 v) {
-        if (rowok && bl < nloc && !((FB_C23_ABL & 8) && v.x != 0x12345u))
+        if (rowok && bl < nloc)
             *reinterpret_cast<uint2 *>(a.a3s + p * a.pl3 + ((size_t)s0 * 25 + ml) * 64 + piece * 8 + 4 * hl) = v;
     });
+}
+
+// fc1 of that path: hfp[ks] = A[M x 1600] x W[1600 x N] over a quarter of K.  One workgroup = 128 rows x 64 columns x
+// 12 or 13 chunks of 32 k (grid z = 4 slices: exactly 256 workgroups at 1024 states and N = 512).  Both operands go
+// through LDS: the activation chunk is fetched as 64-byte row segments (4 lanes per row, not one 16-byte fragment
+// per lane from 64 different lines) into a piece-rotated image, the weight chunk as in conv23_sp_kernel; same
+// software pipeline (fragments of chunk c + 1 read while chunk c is in the MFMAs, chunk c + 2 written to its ring
+// slot, chunk c + 4 in flight from global).  A slice with only 12 chunks runs its 13th on the zero page.
+constexpr int FC1_SP_KS = 4;
+struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; const uint4 *w; float *hfp; int stot, M, N; };
+
+template <int NS>
+__global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
+    constexpr int ASZ = NS * 512, BSZ = 4 * NS * 64, SLOT = ASZ + BSZ;           // uint4 units
+    __shared__ uint4 smem[3 * SLOT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, ks = blockIdx.z;
+    const int cbase = ks * 12 + (ks < 2 ? ks : 2), count = ks < 2 ? 13 : 12;
+    // staging registers as named members (arrays here end up in LDS / scratch: hipcc does not scalarise them)
+    struct St { uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2; };
+    // per-thread source pointers, fixed for the whole K loop: chunk c of the activations is an immediate offset
+    // (64 B per chunk), the weight pointers advance by one chunk per load() (load() is called in chunk order).
+    // Rows past M are clamped to the last row (computed, never stored); a slice with 12 chunks still LOADS a 13th
+    // (the buffers are padded by one chunk) but skips its MFMAs.
+    const int r0 = min(m0 + (int)(threadIdx.x >> 2), a.M - 1), r1 = min(m0 + 64 + (int)(threadIdx.x >> 2), a.M - 1);
+    const uint16_t *pa0 = a.ain + (size_t)r0 * 1600 + (size_t)cbase * 32 + (threadIdx.x & 3) * 8;
+    const uint16_t *pa1 = a.ain + (size_t)r1 * 1600 + (size_t)cbase * 32 + (threadIdx.x & 3) * 8;
+    auto ldA = [&](int c, int p, int i) { return *reinterpret_cast<const uint4 *>((i ? pa1 : pa0) + p * a.aplane + c * 32); };
+    auto pbq = [&](int q) {
+        const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;
+        return a.w + ((size_t)(cbase * 4 + k8) * 3 + pl) * a.N + n0 + lane;
+    };
+    const uint4 *pb0 = pbq(0), *pb1 = pbq(NS == 3 ? 1 : 0), *pb2 = pbq(NS == 3 ? 2 : 0);
+    const size_t bstep = (size_t)12 * a.N;
+    auto ldB = [&](int c, int q) {
+        (void)c;
+        const uint4 *&pb = q == 0 ? pb0 : q == 1 ? pb1 : pb2;
+        const uint4 v = *pb;
+        pb += bstep;
+        return v;
+    };
+    auto load = [&](int c) {
+        St r;
+        r.a0 = ldA(c, 0, 0); r.a1 = ldA(c, 0, 1); r.b0 = ldB(c, 0);
+        if (NS == 3) { r.a2 = ldA(c, 1, 0); r.a3 = ldA(c, 1, 1); r.a4 = ldA(c, 2, 0); r.a5 = ldA(c, 2, 1); r.b1 = ldB(c, 1); r.b2 = ldB(c, 2); }
+        else { r.a2 = r.a0; r.a3 = r.a0; r.a4 = r.a0; r.a5 = r.a0; r.b1 = r.b0; r.b2 = r.b0; }
+        return r;
+    };
+    auto stA_ = [&](int slot, int p, int i, const uint4 v) {
+        const int q = threadIdx.x + 256 * i, row = q >> 2;
+        smem[slot * SLOT + p * 512 + row * 4 + ((q + (row >> 2)) & 3)] = v;
+    };
+    auto store = [&](int slot, const St r) {
+        stA_(slot, 0, 0, r.a0); stA_(slot, 0, 1, r.a1);
+        uint4 *d = smem + slot * SLOT + ASZ + wave * 64 + lane;
+        d[0] = r.b0;
+        if (NS == 3) { stA_(slot, 1, 0, r.a2); stA_(slot, 1, 1, r.a3); stA_(slot, 2, 0, r.a4); stA_(slot, 2, 1, r.a5); d[256] = r.b1; d[512] = r.b2; }
+    };
+    struct Fr { uint4 A[NS]; uint4 W[2][NS]; };           // the fragments of ONE k-step (16 k) of a chunk
+    const int row = wave * 32 + j;
+    auto readF = [&](int slot, int s) {
+        Fr f;
+#pragma unroll
+        for (int p = 0; p < NS; p++) {
+            f.A[p] = smem[slot * SLOT + p * 512 + row * 4 + ((2 * s + hl + (row >> 2)) & 3)];
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) f.W[ct][p] = smem[slot * SLOT + ASZ + ((2 * s + hl) * NS + p) * 64 + ct * 32 + j];
+        }
+        return f;
+    };
+    f32x16 acc[2] = {{0}, {0}};
+    auto compute = [&](const Fr f) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+#define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[pa]), __builtin_bit_cast(bf16x8, f.W[ct][pb]), acc[ct], 0, 0, 0)
+            if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }
+            FB_M(0, 0);
+#undef FB_M
+        }
+    };
+    St stA = load(0), stB = load(1);
+    store(0, stA); stA = load(2);
+    __syncthreads();
+    store(1, stB); stB = load(3);
+    Fr cur = readF(0, 0);
+    __syncthreads();
+    // half-chunk software pipeline: the fragments of the next k-step are read while the 12 MFMAs of this one run
+#define FB_STEP(cc, ST)                                                                                    \
+    {                                                                                                          \
+        const Fr f1 = readF((cc) % 3, 1);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        compute(cur);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        const Fr nx = readF(((cc) + 1) % 3, 0);                                                                \
+        if ((cc) + 2 < 13) { store(((cc) + 2) % 3, ST); if ((cc) + 4 < 13) ST = load((cc) + 4); }              \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        compute(f1);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        __syncthreads();                                                                                       \
+        cur = nx;                                                                                              \
+    }
+#pragma unroll
+    for (int c = 0; c < 12; c += 2) { FB_STEP(c, stA); FB_STEP(c + 1, stB); }
+    if (count > 12) { compute(cur); compute(readF(0, 1)); }            // chunk 12 sits in ring slot 12 % 3
+#undef FB_STEP
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mr = m0 + wave * 32 + drow(r, lane);
+            if (mr < a.M) a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = acc[ct][r];
+        }
 }
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
@@ -1341,7 +1311,7 @@ struct fb_qnet {
     uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
     bool wsp_stale[2];               // parameters changed since wsp was built
     uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
-    uint16_t *a1s, *a2s, *a3s;       // activation planes of that path: [3][S*3200], [3][S*1600], [3][S*1600] bf16
+    uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [3][S*3200], conv3 out [3][S*1600] bf16
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
     AdamDev *adam;
     // workspace for 3 * max_batch samples
@@ -1380,11 +1350,11 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
-    const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)200 * 3 * fc_width) * sizeof(uint4);
+    const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)(200 + 4) * 3 * fc_width) * sizeof(uint4);   // + one chunk: fc1_sp_kernel over-reads
     alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
     h->wsp_stale[0] = h->wsp_stale[1] = true; h->nsplit = 3;
     alloc((void **)&h->zeros, 256);
-    alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a2s, S * 1600 * 6); alloc((void **)&h->a3s, S * 1600 * 6);
+    alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a3s, S * 1600 * 6 + 256);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
     alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
@@ -1402,7 +1372,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
-    void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a2s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+    void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -1518,11 +1488,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
-#ifdef FB_CONV1_OLD
-        if (false) {
-#else
         if (sp) {
-#endif
             // persistent: every wave takes `rounds` tiles, about 3 workgroups per CU
             const int rounds = (t1 + 3071) / 3072, gsp = (t1 + 4 * rounds - 1) / (4 * rounds);
             if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit);
@@ -1532,34 +1498,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     const int stot = 3 * h->max_batch;
     if (sp) {
-        const int M = maxc * 25;
-        SpArgs a2{h->a1s, pl1, h->zeros, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, h->a2s, pl2, nullptr, 0, M, 64};
-        SpArgs a3{h->a2s, pl2, h->zeros, h->wsp[p.which] + WSP_W3, p.sl.s[0].params + OFF_B3, h->a3s, pl2, nullptr, 0, M, 64};
-        SpArgs a4{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, nullptr, nullptr, 0, h->hf, stot, maxc, h->FC};
-        const dim3 g23((M + 127) / 128, 1, 1), g4((maxc + 127) / 128, h->FC / 64, FC1_KS);
         C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc};
-        const dim3 gc((maxc + 4) / 5);
-#ifdef FB_SP_UNFUSED
-        (void)c23; (void)gc;
-#else
-        (void)a2; (void)a3; (void)g23;
-#endif
+        Fc1Args af{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, h->hf, stot, maxc, h->FC};
+        const dim3 gc((maxc + 4) / 5), gf((maxc + 127) / 128, h->FC / 64, FC1_SP_KS);
         if (h->nsplit == 3) {
-#ifdef FB_SP_UNFUSED
-            FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 3, SPG>), g23, dim3(256 * SPG), 0, st, a2);
-            FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 3, SPG>), g23, dim3(256 * SPG), 0, st, a3);
-#else
             FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
-#endif
-            FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 3, SPG>), g4, dim3(256 * SPG), 0, st, a4);
+            FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
         } else {
-#ifdef FB_SP_UNFUSED
-            FB_K(K_CONV2) hipLaunchKernelGGL((sp_gemm_kernel<2, 1, SPG>), g23, dim3(256 * SPG), 0, st, a2);
-            FB_K(K_CONV3) hipLaunchKernelGGL((sp_gemm_kernel<3, 1, SPG>), g23, dim3(256 * SPG), 0, st, a3);
-#else
             FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(256), 0, st, c23);
-#endif
-            FB_K(K_FC1) hipLaunchKernelGGL((sp_gemm_kernel<4, 1, SPG>), g4, dim3(256 * SPG), 0, st, a4);
+            FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
         }
     }
     if (!sp) FB_K(K_CONV2) {
@@ -1576,7 +1523,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     FB_K(K_HEAD) {
         HeadArgs H;
-        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = sp ? FC1_KS : big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
+        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
         H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
         H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
         H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
