@@ -174,18 +174,19 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC bytes per launch, rocprofv3 --pmc passes
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
 
-        def add(name, us, per_step, bound, work):
-            # conv1 runs on the bf16 matrix cores (3 bf16 MFMAs per exact fp32 product): price its
-            # ALGORITHMIC flops against the bf16 dense peak; it executes 3x that many bf16 flops
-            bf16 = name.startswith("conv1_pool_kernel")
-            peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF)
+        def add(name, us, per_step, bound, work, split=0):
+            # split = s > 0: the kernel computes fp32 products as s bf16 x bf16 MFMA products:
+            # conv1 3 (u8 input is exact in bf16), the split-bf16 acting kernels 6.  Their ALGORITHMIC flops are
+            # priced against the bf16 dense peak; they execute s times that many bf16 flops (executed_frac).
+            split = split or (3 if name.startswith("conv1_pool_kernel") else 0)
+            peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF)
             ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
             k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
                  "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                  "frac": round(ach / peak, 5), "traffic": pmc.get(name)}
-            if bf16:
-                k["dtype"] = "bf16x3 (exact fp32 result)"
-                k["executed_frac"] = round(3 * ach / peak, 5)
+            if split:
+                k["dtype"] = f"bf16x{split} (fp32 result)"
+                k["executed_frac"] = round(split * ach / peak, 5)
             kernels.append(k)
 
         scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
@@ -200,11 +201,14 @@ def main():
         st = L.current_stream
         # acting forward, n = 1024
         scratch.act_nib(nib, 0.0)
-        for k in range(5):
-            name = lib.fb_qnet_kernel_name(k).decode()
+        # (>= 256 states, forward only: the split-bf16 kernels; conv3 rides in conv2's launch)
+        act = [(0, "conv1_sp_kernel<nib>", FWD_FLOP["conv1_pool_kernel"], 3),
+               (1, "conv23_sp_kernel", FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"], 6),
+               (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 6), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]
+        for k, name, flop, split in act:
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
                                                                   None, None, st()), "profile"), R)
-            add(name + "[act n=1024]", us, 1, "mfma", FWD_FLOP[name] * N_ENVS)
+            add(name + "[act n=1024]", us, 1, "mfma", flop * N_ENVS, split)
         # train step, B = 32 (forward kernels see 2B samples: s and s')
         scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
         for k in range(64):

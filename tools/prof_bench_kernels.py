@@ -6,14 +6,14 @@ from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
 n, B = 1024, 32
 env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n), QNet(max_batch=n)
 net.init_params(0)
+nib = env.track_state()
 env.observe(); replay.reset(env.frame_bits)
 acts = (torch.rand(n, device="cuda") < 0.1).to(torch.uint8)
 for t in range(40):                                   # fill a little of the ring
     env.frame_step(acts, want_u8=False)
     replay.push(env.frame_bits, acts, env.reward, env.terminal)
 for t in range(5):
-    states = replay.current_state()
-    a = net.act(states, 0.03, step=t)
+    a = net.act_nib(nib, 0.03, step=t)
     env.frame_step(a, want_u8=False)
     replay.push(env.frame_bits, a, env.reward, env.terminal)
     idx, _ = replay.sample(B)

@@ -8,7 +8,8 @@ dur, gap, cnt = collections.defaultdict(float), collections.defaultdict(float), 
 order = []
 prev_end = None
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0][:60] + " g" + r.get("Grid_Size_X", r.get("Grid_Size", "?")) + " wg" + r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))
+    nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+    k = nm.split("(")[0][:44] + " g" + r.get("Grid_Size_X", r.get("Grid_Size", "?")) + " wg" + r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if k not in cnt: order.append(k)
     cnt[k] += 1; dur[k] += e - s
