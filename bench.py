@@ -238,6 +238,27 @@ def main():
         add("gather_kernel<true>[currentState n=1024]", us, 0, "hbm", 2 * 25_600 * N_ENVS)
         us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
         add("env_kernel<true>[n=1024]", us, 1, "hbm", ENV_BYTES * N_ENVS)
+        # prioritized replay (config 4: 1 M-slot SumTree in HBM): latency-bound tree walks -> us per batch, no BW fraction
+        per = VecReplay(CAPACITY, N_ENVS, prioritized=True)
+        per.seed(seed, "numpy")
+        per.reset(env.frame_bits)
+        for _ in range(64):                                  # 65 536 stored transitions, priorities all at the store maximum
+            per.push(env.frame_bits, acts, env.reward, env.terminal)
+        pidx, _ = per.sample(BATCH)
+        perr = torch.rand(BATCH, device="cuda")
+        per.update_priorities(pidx, abs_err=perr)
+        us = ev_time(lambda: [per.sample(BATCH) for _ in range(R)], R)
+        add("per_sample_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        us = ev_time(lambda: [per.update_priorities(pidx, abs_err=perr) for _ in range(R)], R)
+        add("per_update_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        us = ev_time(lambda: [per.push(env.frame_bits, acts, env.reward, env.terminal) for _ in range(R)], R)
+        add("push_kernel + per_store_kernel[n=1024, exact order]", us, 0, "hbm", 0)
+        per.set_per_mode("fast")                             # level-wise recomputation instead of ordered running sums
+        us = ev_time(lambda: [per.push(env.frame_bits, acts, env.reward, env.terminal) for _ in range(R)], R)
+        add("push_kernel + per_store_fast_kernel[n=1024]", us, 0, "hbm", 0)
+        us = ev_time(lambda: [per.update_priorities(pidx, abs_err=perr) for _ in range(R)], R)
+        add("per_update_fast_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        del per
         dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
         roofline = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}
         roofline["us"] = dom["us"]
@@ -258,6 +279,19 @@ def main():
                "sample": f"oracle single-env loop of FlappyBirdDQN.py:72-76 (batch-1 act, full render + preprocess, "
                          f"store, random.sample(32), train): {res['env_steps']} env steps incl. {res['grad_steps']} "
                          f"train steps in {res['seconds']:.1f} s, fp64-accumulating scalar C, 1 thread, no 30 FPS cap"}
+        # (ii) all host cores: the reference has ONE env and ONE session, so "all cores" = that many independent
+        # replicas of the same loop (one per core, no shared state); the 30 FPS cap of the reference (tick(30),
+        # wrapped_flappy_bird.py:179) bounds each replica at 30 env-steps/s and 30 grad-steps/s analytically.
+        import concurrent.futures as cf
+        ncpu = min(len(os.sched_getaffinity(0)), 16)         # the box's CPU share for one GPU is 16 cores
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(ncpu) as ex:              # ctypes releases the GIL inside the C loop
+            rs = list(ex.map(lambda i: orc.reference_loop(observe_steps=100, train_steps=20, replay_cap=50000, seed=i), range(ncpu)))
+        wall = time.perf_counter() - t0
+        cpu["all_cores"] = {"cores": ncpu, "value": round(sum(r["env_steps"] for r in rs) / wall, 2), "unit": "env-steps/s",
+                            "grad_steps_per_sec": round(sum(r["grad_steps"] for r in rs) / wall, 3),
+                            "sample": f"{ncpu} independent replicas (100 observe + 20 train steps each) in {wall:.1f} s",
+                            "fps_capped_bound": {"env_steps_per_s": 30 * ncpu, "grad_steps_per_s": 30 * ncpu}}
 
     if rank == 0:
         out = {

@@ -17,6 +17,8 @@ RNG_CPYTHON, RNG_PHILOX, RNG_NUMPY = 0, 1, 2
 ARCH_PLAIN, ARCH_DUELING = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
 ALGO_DQN, ALGO_NATURE, ALGO_DOUBLE, ALGO_PER = 0, 1, 2, 3
+DTYPE_F32, DTYPE_BF16 = 0, 1
+PER_EXACT, PER_FAST = 0, 1
 
 _vp, _i, _i64, _u64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
@@ -47,6 +49,7 @@ SIGNATURES = {
     "fb_replay_gather": [_vp, _i] + [_vp] * 7,
     "fb_replay_profile_gather": [_vp, _i] + [_vp] * 6 + [_i, _vp],
     "fb_replay_update_priorities": [_vp, _i, _vp, _vp, _vp, _vp],
+    "fb_replay_set_per_mode": [_vp, _i],
     "fb_replay_size": [_vp, _vp],
     "fb_replay_per_tree": [_vp] * 5,
     "fb_qnet_create": [_i, _i, _i, _i, _vp],
@@ -58,6 +61,7 @@ SIGNATURES = {
     "fb_qnet_get_adam_state": [_vp] * 4,
     "fb_qnet_set_adam_state": [_vp] * 4,
     "fb_qnet_set_hparams": [_vp, _f, _f, _f, _f],
+    "fb_qnet_set_inference_dtype": [_vp, _i],
     "fb_qnet_forward": [_vp, _i, _vp, _i, _vp, _vp],
     "fb_qnet_act": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],
     "fb_qnet_act_nib": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],

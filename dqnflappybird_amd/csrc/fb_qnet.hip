@@ -1397,6 +1397,12 @@ extern "C" int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float bet
     return FB_OK;
 }
 
+extern "C" int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype) {
+    FB_REQUIRE(h && (dtype == FB_DTYPE_F32 || dtype == FB_DTYPE_BF16), "fb_qnet_set_inference_dtype: dtype must be FB_DTYPE_F32 or FB_DTYPE_BF16");
+    h->nsplit = dtype == FB_DTYPE_BF16 ? 1 : 3;
+    return FB_OK;
+}
+
 extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *stream) {
     FB_REQUIRE(h && (which == 0 || which == 1), "fb_qnet_init_params: bad argument");
     hipLaunchKernelGGL(init_params_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, fb_stream(stream),

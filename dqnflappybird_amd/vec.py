@@ -181,6 +181,11 @@ class VecReplay:
         L.check(L.lib().fb_replay_update_priorities(self.h, idx.numel(), L.ptr(idx), L.ptr(abs_err), L.ptr(priorities),
                                                     L.current_stream()), "fb_replay_update_priorities")
 
+    def set_per_mode(self, mode="exact"):
+        """'exact' (reference-order running sums, bit-identical tree) or 'fast' (level-wise recomputation)."""
+        L.check(L.lib().fb_replay_set_per_mode(self.h, {"exact": L.PER_EXACT, "fast": L.PER_FAST}[mode]),
+                "fb_replay_set_per_mode")
+
     def __len__(self):
         v = C.c_int64()
         L.check(L.lib().fb_replay_size(self.h, C.byref(v)), "fb_replay_size")
@@ -246,6 +251,11 @@ class QNet:
 
     def set_hparams(self, lr=1e-6, beta1=0.9, beta2=0.999, eps=1e-8):
         L.check(L.lib().fb_qnet_set_hparams(self.h, lr, beta1, beta2, eps), "fb_qnet_set_hparams")
+
+    def set_inference_dtype(self, dtype="f32"):
+        """'f32' (default) or 'bf16': arithmetic of forward / act / act_nib on >= 256 states (BASELINE config 3)."""
+        L.check(L.lib().fb_qnet_set_inference_dtype(self.h, {"f32": L.DTYPE_F32, "bf16": L.DTYPE_BF16}[dtype]),
+                "fb_qnet_set_inference_dtype")
 
     def adam_state(self):
         m = torch.empty(self.n_params, dtype=torch.float32, device=self.device)

@@ -146,6 +146,16 @@ int fb_replay_profile_gather(fb_replay_t h, int batch, const int64_t *idx, uint8
  * computing (min(|e|+0.01, 1))^0.6 on the device. */
 int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err,
                                 const float *priorities_or_null, void *stream);
+/* How the SumTree is maintained (prioritized memories only):
+ *   FB_PER_EXACT (default) the reference's running sums in the reference's update order: tree bytes and sampled
+ *                indices bit-identical to BrainPrioritizedReplyDQN.SumTree (the parity mode); Memory.store of
+ *                N envs costs N ordered tree walks
+ *   FB_PER_FAST  every touched node recomputed as left + right, level by level: order independent, same values
+ *                up to fp64 rounding of the sums, ~20x faster stores for thousands of envs.  Switch only while the
+ *                memory is empty or between steps; the tree stays valid in both modes. */
+#define FB_PER_EXACT 0
+#define FB_PER_FAST 1
+int fb_replay_set_per_mode(fb_replay_t h, int mode);
 /* host-side queries (synchronous): len(replayMemory); PER: tree copy f64[2*cap-1] [host] */
 int fb_replay_size(fb_replay_t h, int64_t *size_host);
 int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *data_pointer, int64_t *size, double *beta);
@@ -185,6 +195,13 @@ int fb_qnet_store_params(fb_qnet_t h, int which, float *flat /*[dev]*/, void *st
 int fb_qnet_get_adam_state(fb_qnet_t h, float *m, float *v, float *beta_pows_host);
 int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *v, const float *beta_pows_host);
 int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float eps);
+/* Arithmetic of the forward-only path on >= 256 states (fb_qnet_forward / fb_qnet_act / fb_qnet_act_nib):
+ *   FB_DTYPE_F32  (default) fp32-equivalent: every fp32 product as six bf16 MFMA products of hi/mid/lo planes
+ *   FB_DTYPE_BF16 plain bf16 inference (config 3 of BASELINE.json: "bf16"): activations and weights rounded to
+ *                 bf16, fp32 accumulation.  Training and batches < 256 always compute in fp32. */
+#define FB_DTYPE_F32 0
+#define FB_DTYPE_BF16 1
+int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype);
 /* QValue.eval: states u8[B,80,80,4] -> q f32[B,A] */
 int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream);
 /* getAction for N envs: forward + epsilon-greedy (Philox stream 1, counter = step).

@@ -71,6 +71,35 @@ def test_large_batch_forward_split_bf16_path(torch_cuda, oracle, dueling, N):
     assert np.abs(q - want).max() <= 4 * np.abs(q32 - want).max() + 1e-7
 
 
+def test_bf16_inference_mode(torch_cuda, oracle):
+    """BASELINE config 3's dtype: plain bf16 operands (hi planes only), fp32 accumulation, on the >= 256-state
+    forward path.  bf16 keeps 8 significant bits, so the bound is relative (3 % of the Q scale); the greedy
+    actions still agree with the fp32 ones except where the two Q-values are closer than that."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet
+    rng = np.random.default_rng(77)
+    cfg = oracle.qcfg()
+    p = trained_like_params(oracle, cfg, seed=3)
+    net = QNet(max_batch=512)
+    net.load_params(p)
+    s = rand_states(rng, 512)
+    sd = torch.from_numpy(s).cuda()
+    q32 = net.forward(sd).cpu().numpy()
+    net.set_inference_dtype("bf16")
+    q16 = net.forward(sd).cpu().numpy()
+    net.set_inference_dtype("f32")
+    assert np.array_equal(net.forward(sd).cpu().numpy(), q32)          # switching back restores the fp32 path
+    scale = np.abs(q32).max()
+    err = np.abs(q16 - q32).max()
+    assert 0 < err <= 0.03 * scale
+    margin = np.abs(q32[:, 0] - q32[:, 1])
+    agree = q16.argmax(1) == q32.argmax(1)
+    assert agree[margin > 0.06 * scale].all()
+    with pytest.raises(ValueError):
+        from dqnflappybird_amd import _lib as L
+        L.check(L.lib().fb_qnet_set_inference_dtype(net.h, 7), "fb_qnet_set_inference_dtype")
+
+
 def oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw):
     q, acts = oracle.forward(p_on, cfg, s, keep=True)
     if algo == "dqn":

@@ -236,6 +236,61 @@ def test_per_vector_store_equals_sequential(torch_cuda, golden):
     assert np.array_equal(tree.view(np.uint64), mem.tree.view(np.uint64))
 
 
+@pytest.mark.parametrize("N,cap", [(997, 50000), (4096, 100000), (64, 300)])
+def test_per_fast_mode_tree_is_the_exact_pairwise_sum(torch_cuda, N, cap):
+    """FB_PER_FAST keeps the heaps by recomputation (node = left + right), not by the reference's running
+    sums: the LEAVES, pointer and size are those of the reference-order oracle, every internal node is the
+    correctly rounded sum of its two children (so the root is within fp64 rounding of the oracle's total),
+    and the sampled indices are exactly what SumTree.get_leaf returns on the device's own tree."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    from oracle import oracle as o
+    rep = VecReplay(cap, N, prioritized=True)
+    rep.set_per_mode("fast")
+    z8 = torch.zeros((N, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    mem = o.Memory(cap)
+    rng = np.random.default_rng(N)
+
+    def get_leaf(tree, v):                        # BrainPrioritizedReplyDQN.py:85-100
+        i = 0
+        while 2 * i + 1 < len(tree):
+            l = 2 * i + 1
+            if v <= tree[l]:
+                i = l
+            else:
+                v -= tree[l]
+                i = l + 1
+        return i
+
+    for step in range(2 * cap // N + 3):           # wraps the ring, crosses the leaf-depth split
+        rep.push(z8, za, zr, za)
+        mem.store(N)
+        if step % 5 == 2:
+            tree, _, _, _ = rep.per_state()
+            u = rng.random(32)
+            idx, isw = rep.sample(32, uniforms=torch.from_numpy(u).cuda())
+            seg = tree[0] / 32                     # Memory.sample: v = uniform(seg*i, seg*(i+1)) with the injected u
+            want = [get_leaf(tree, seg * i + (seg * (i + 1) - seg * i) * u[i]) for i in range(32)]
+            assert idx.cpu().tolist() == want
+            ps = (rng.random(32).astype(np.float32) * 1.2 + 0.01).clip(max=1.0) ** np.float32(0.6)
+            ps[5] = ps[0]
+            idx[5] = idx[0]                        # a duplicate index: the later entry wins in both
+            rep.update_priorities(idx, priorities=torch.from_numpy(ps).cuda())
+            mem.batch_update_p(idx.cpu().numpy(), ps)
+    tree, ptr, size, beta = rep.per_state()
+    assert (ptr, size) == (mem.data_pointer, mem.size)
+    assert np.array_equal(tree[cap - 1:].view(np.uint64), mem.tree[cap - 1:].view(np.uint64))      # leaves
+    inner = np.arange(cap - 1)
+    assert np.array_equal(tree[inner], tree[2 * inner + 1] + tree[2 * inner + 2])                  # exact fp64 sums
+    assert abs(tree[0] - mem.tree[0]) <= 1e-9 * mem.tree[0]
+    rep.set_per_mode("exact")                      # the tree stays valid for the exact kernels
+    rep.push(z8, za, zr, za)
+    t2, _, _, _ = rep.per_state()
+    assert abs(t2[0] - t2[cap - 1:].sum()) <= 1e-9 * t2[0]
+
+
 def test_per_device_pow_close_to_numpy(torch_cuda, golden):
     """abs_err path: (min(|e|+0.01, 1))^0.6 computed on the device, within 1 fp32 ulp of NumPy's
     (which itself is not correctly rounded), and abs_err updated in place like the reference."""
