@@ -44,6 +44,7 @@ SIGNATURES = {
     "fb_replay_seed": [_vp, _i, _u64],
     "fb_replay_reset": [_vp, _vp, _vp, _vp],
     "fb_replay_push": [_vp] * 7,
+    "fb_replay_push_sample": [_vp] * 6 + [_i, _vp, _vp],
     "fb_replay_current_state": [_vp, _vp, _vp],
     "fb_replay_sample": [_vp, _i, _vp, _vp, _vp, _vp],
     "fb_replay_gather": [_vp, _i] + [_vp] * 7,

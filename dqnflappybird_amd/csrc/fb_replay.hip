@@ -184,14 +184,12 @@ __device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
 // consumed exactly like CPython consumes them (every getrandbits call, also rejected / duplicate ones, up
 // to and including the word that completed the sample).  Pool path (n <= setsize): the modulus shrinks
 // with every draw, so it stays word-serial.  Lane (i & 63) keeps result i in register slot i >> 6.
-__global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
-                                                            long long *__restrict__ out) {
-    __shared__ uint32_t mt[624];
-    __shared__ int pool[1100];
+__device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k, long long setsize, long long steps,
+                                                    long long *__restrict__ out, uint32_t *mt, int *pool) {
     const int lane = threadIdx.x;
     for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
     uint32_t idx = P.mt->idx;
-    const long long total = P.dev->steps * P.n_envs;
+    const long long total = steps * P.n_envs;
     const long long n = total < P.cap ? total : P.cap;
     if (k > n || k > MAXB) {
         if (lane == 0) P.dev->error = 2;                // "Sample larger than population"
@@ -244,6 +242,43 @@ __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int 
     for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
     for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];
     if (lane == 0) P.mt->idx = idx;
+}
+
+__global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
+                                                            long long *__restrict__ out) {
+    __shared__ uint32_t mt[624];
+    __shared__ int pool[1100];
+    sample_cpython_body(P, k, setsize, P.dev->steps, out, mt, pool);
+}
+
+// fb_replay_push_sample: Memory append + random.sample in ONE launch.  The sample only needs the size the
+// memory will have after the push (known on the host), not the pushed data, so it rides as one extra
+// workgroup beside the copy workgroups: the ~10 us single-wave sampler leaves the step's critical path.
+__global__ __launch_bounds__(64) void push_sample_kernel(ReplayParams P, long long steps, const uint8_t *__restrict__ frames,
+                                                         const unsigned long long *__restrict__ fbits,
+                                                         const uint8_t *__restrict__ a, const float *__restrict__ r,
+                                                         const uint8_t *__restrict__ t, int k, long long setsize,
+                                                         long long *__restrict__ out) {
+    __shared__ uint32_t mt[624];
+    __shared__ int pool[1100];
+    if (blockIdx.x == gridDim.x - 1) { sample_cpython_body(P, k, setsize, steps + 1, out, mt, pool); return; }
+    const int lane = threadIdx.x;
+    for (int e = blockIdx.x; e < P.n_envs; e += gridDim.x - 1) {
+        unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
+        if (fbits) {
+            for (int w = lane; w < WORDS; w += 64) dst[w] = fbits[(size_t)e * WORDS + w];
+        } else {
+            for (int w = 0; w < WORDS; w++) {
+                const unsigned long long m = __ballot(frames[(size_t)e * 6400 + w * 64 + lane] != 0);
+                if (lane == 0) dst[w] = m;
+            }
+        }
+        if (lane == 0) {
+            const size_t mo = (size_t)(steps % P.t_f) * P.n_envs + e;
+            P.act[mo] = a[e]; P.rew[mo] = r[e]; P.term[mo] = t[e];
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0) P.dev->steps = steps + 1;
 }
 
 __global__ void sample_philox_kernel(ReplayParams P, int k, long long *__restrict__ out) {
@@ -677,6 +712,32 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
     return FB_OK;
 }
 
+static long long cpython_setsize(int batch) {
+    // Lib/random.py: setsize = 21; if k > 5: setsize += 4 ** _ceil(_log(k * 3, 4))
+    long long setsize = 21;
+    if (batch > 5) setsize += (long long)pow(4.0, ceil(log((double)batch * 3.0) / log(4.0)));
+    return setsize;
+}
+
+extern "C" int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
+                                     const float *rewards, const uint8_t *terminals, int batch, int64_t *idx, void *stream) {
+    FB_REQUIRE(h && actions && rewards && terminals && idx, "fb_replay_push_sample: NULL argument");
+    FB_REQUIRE((frames != nullptr) != (frame_bits != nullptr), "fb_replay_push_sample: give exactly one of frames / frame_bits");
+    FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_push_sample: batch must be in 1..%d", MAXB);
+    ReplayParams &P = h->P;
+    if (P.kind != FB_REPLAY_UNIFORM || P.rng_kind != FB_RNG_CPYTHON) {       // nothing to fuse: the two calls in a row
+        int rc = fb_replay_push(h, frames, frame_bits, actions, rewards, terminals, stream);
+        if (rc != FB_OK) return rc;
+        return fb_replay_sample(h, batch, nullptr, idx, nullptr, stream);
+    }
+    hipLaunchKernelGGL(push_sample_kernel, dim3((P.n_envs < 512 ? P.n_envs : 512) + 1), dim3(64), 0, fb_stream(stream), P, h->host_steps,
+                       frames, (const unsigned long long *)frame_bits, actions, rewards, terminals, batch, cpython_setsize(batch),
+                       (long long *)idx);
+    FB_LAUNCH_CHECK();
+    h->host_steps += 1;
+    return FB_OK;
+}
+
 extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream) {
     FB_REQUIRE(h && states, "fb_replay_current_state: NULL argument");
     ReplayParams &P = h->P;
@@ -699,10 +760,7 @@ extern "C" int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms
     } else if (P.rng_kind == FB_RNG_PHILOX) {
         hipLaunchKernelGGL(sample_philox_kernel, dim3(1), dim3(256), 0, st, P, batch, (long long *)idx);
     } else {
-        // Lib/random.py: setsize = 21; if k > 5: setsize += 4 ** _ceil(_log(k * 3, 4))
-        long long setsize = 21;
-        if (batch > 5) setsize += (long long)pow(4.0, ceil(log((double)batch * 3.0) / log(4.0)));
-        hipLaunchKernelGGL(sample_cpython_kernel, dim3(1), dim3(64), 0, st, P, batch, setsize, (long long *)idx);
+        hipLaunchKernelGGL(sample_cpython_kernel, dim3(1), dim3(64), 0, st, P, batch, cpython_setsize(batch), (long long *)idx);
     }
     FB_LAUNCH_CHECK();
     return FB_OK;

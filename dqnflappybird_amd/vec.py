@@ -144,6 +144,17 @@ class VecReplay:
         L.check(L.lib().fb_replay_push(self.h, L.ptr(f), L.ptr(b), L.ptr(actions), L.ptr(rewards), L.ptr(terminals),
                                        L.current_stream()), "fb_replay_push")
 
+    def push_sample(self, next_frames, actions, rewards, terminals, batch):
+        """push(...) then sample(batch) of a uniform memory in one launch (fb_replay_push_sample) -> idx int64[B]."""
+        if self.prioritized:
+            raise ValueError("push_sample is for uniform memories (PER needs the importance weights: push + sample)")
+        f, b = self._split(next_frames)
+        _dev_check(actions, rewards, terminals)
+        idx = self._get(f"idx{batch}", (batch,), torch.int64)
+        L.check(L.lib().fb_replay_push_sample(self.h, L.ptr(f), L.ptr(b), L.ptr(actions), L.ptr(rewards), L.ptr(terminals),
+                                              batch, L.ptr(idx), L.current_stream()), "fb_replay_push_sample")
+        return idx
+
     def _get(self, name, shape, dtype):
         t = self._buf.get(name)
         if t is None or tuple(t.shape) != tuple(shape):

@@ -41,10 +41,12 @@ class VecBrain:
         self.episodes = torch.zeros((), dtype=torch.int64, device="cuda")
         self.last_loss = None
 
-    def train_step(self):
+    def train_step(self, idx=None):
         if self.algo in ("nature", "double") and self.timeStep % self.replace_target_iter == 0:
             self.net.sync_target()
-        idx, isw = self.replay.sample(self.batch)
+        isw = None
+        if idx is None:
+            idx, isw = self.replay.sample(self.batch)
         s, a, r, s2, t = self.replay.gather(idx)
         loss, abs_err, _ = self.net.train_step(self.algo, s, a, r, s2, t, isw=isw, gamma=self.gamma, flat_grad=self.grad,
                                                want_aux=self.algo == "per")
@@ -60,10 +62,15 @@ class VecBrain:
         if self.epsilon > self.final_epsilon and self.onlineTimeStep > self.observe:
             self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
         _, reward, terminal, _ = self.env.frame_step(actions, want_u8=False)
-        self.replay.push(self.env.frame_bits, actions, reward, terminal)
+        training = self.onlineTimeStep > self.observe
+        idx = None
+        if training and self.algo != "per":                  # store + random.sample in one launch (same indices)
+            idx = self.replay.push_sample(self.env.frame_bits, actions, reward, terminal, self.batch)
+        else:
+            self.replay.push(self.env.frame_bits, actions, reward, terminal)
         self.episodes += terminal.sum()
-        if self.onlineTimeStep > self.observe:
-            self.train_step()
+        if training:
+            self.train_step(idx)
         self.timeStep += 1
         self.onlineTimeStep += 1
 

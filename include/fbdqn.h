@@ -129,6 +129,13 @@ int fb_replay_reset(fb_replay_t h, const uint8_t *frames /*[dev] u8[N,80,80] or 
  * must not be replayed from a captured hipGraph. */
 int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
                    const float *rewards, const uint8_t *terminals, void *stream);
+/* fb_replay_push followed by fb_replay_sample(batch) of a uniform memory, in one launch: identical results
+ * (the sample depends on the memory's size after the push, not on the pushed data; same RNG consumption),
+ * but the single-wave sampler runs beside the copy instead of after it.  idx i64[batch] [dev].  For a
+ * prioritized memory or a non-CPython RNG it simply performs the two calls in a row (isw is not returned:
+ * use the separate calls for PER). */
+int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
+                          const float *rewards, const uint8_t *terminals, int batch, int64_t *idx, void *stream);
 /* currentState of every env: u8[N,80,80,4] [dev] (newest frame last). */
 int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream);
 /* Uniform: idx = deque positions (0 = oldest) exactly as random.sample(range(len), B).

@@ -119,6 +119,35 @@ def test_cpython_sample_large_memories(torch_cuda, golden, n):
                 assert idx.cpu().tolist() == list(want)
 
 
+def test_push_sample_equals_push_then_sample(torch_cuda):
+    """fb_replay_push_sample (sampler as an extra workgroup of the push launch) == the two calls in a row:
+    same indices, same MT19937 consumption, same ring contents -- also across the ring wrap and for u8 frames."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    N, cap, B = 7, 300, 32
+    a_, b_ = VecReplay(cap, N), VecReplay(cap, N)
+    a_.seed(11, "cpython"); b_.seed(11, "cpython")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    first = (torch.rand((N, 80, 80), device="cuda", generator=g) < 0.4).to(torch.uint8) * 255
+    a_.reset(first); b_.reset(first)
+    for step in range(120):
+        fr = (torch.rand((N, 80, 80), device="cuda", generator=g) < 0.4).to(torch.uint8) * 255
+        ac = (torch.rand(N, device="cuda", generator=g) < 0.5).to(torch.uint8)
+        rw = torch.rand(N, device="cuda", generator=g)
+        tm = (torch.rand(N, device="cuda", generator=g) < 0.1).to(torch.uint8)
+        if (step + 1) * N < B:                     # too few transitions for a sample of 32: plain pushes
+            a_.push(fr, ac, rw, tm); b_.push(fr, ac, rw, tm)
+            continue
+        a_.push(fr, ac, rw, tm)
+        ia, _ = a_.sample(B)
+        ib = b_.push_sample(fr, ac, rw, tm, B)
+        assert ia.cpu().tolist() == ib.cpu().tolist()
+        if step % 17 == 0:
+            for x, y in zip(a_.gather(ia), b_.gather(ib)):
+                assert torch.equal(x, y)
+    assert len(a_) == len(b_) == cap
+
+
 def test_sample_larger_than_population_fails_loudly(torch_cuda):
     torch = torch_cuda
     from dqnflappybird_amd.vec import VecReplay
