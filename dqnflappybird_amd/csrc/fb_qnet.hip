@@ -443,8 +443,7 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
 // NS = 3: the fp32-equivalent path; NS = 1 uses the hi planes only = plain bf16 inference.
 constexpr int WSP_W2 = 0, WSP_W3 = 64 * 3 * 64, WSP_WF1 = WSP_W3 + 72 * 3 * 64;     // uint4 offsets inside wsp
 
-__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wsplit_item(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, int id) {
     const float *W; uint4 *out; int N;
     if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
     else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
@@ -460,6 +459,10 @@ __global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restric
     o[2 * N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
+__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC) {
+    wsplit_item(params, wsp, FC, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
 // L1/L2 traffic at 1024 states); here a workgroup parks them in LDS once and its waves walk over tiles, the
 // next tile's input bytes in flight while the current one is in the MFMAs.  Operands are swapped (D = W^T x A^T):
@@ -472,17 +475,23 @@ __device__ __forceinline__ float quad_max(float v) {
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
 }
 
-#ifndef FB_C1_ABL
-#define FB_C1_ABL 0
-#endif
 #ifndef FB_C1_WAVES
 #define FB_C1_WAVES 3
 #endif
+// The first `nws` workgroups of the launch do not convolve: they re-split W_conv2 / W_conv3 / W_fc1 for the kernels
+// that follow (wsplit_item; only when the step changed the parameters) -- one launch and its cold start less.
+constexpr int WS_BLOCKS = 64;
 template <bool NIB>
 __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
-                                                                     size_t p1plane, int nsplit) {
+                                                                     size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int nws) {
     __shared__ uint4 wl[3 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
+    if ((int)blockIdx.x < nws) {
+        const int items = 64 * 64 + 72 * 64 + 200 * FC;
+        for (int id = blockIdx.x * 256 + threadIdx.x; id < items; id += nws * 256) wsplit_item(s.params, wsp, FC, id);
+        return;
+    }
+    const int bid = blockIdx.x - nws, nblk = gridDim.x - nws;
     for (int q = threadIdx.x; q < 3 * 16 * 64; q += 256) wl[q] = reinterpret_cast<const uint4 *>(s.w1s)[q];
     if (NIB) {
         const unsigned t = threadIdx.x;
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     __syncthreads();
     typedef typename std::conditional<NIB, unsigned, uint2>::type Raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31, pp = j >> 2, pos = j & 3;
-    const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = gridDim.x * 4;
+    const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = nblk * 4;
     float b4[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) b4[e] = s.params[OFF_B1 + 8 * pos + 4 * hl + e];
@@ -518,14 +527,12 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
             }
         }
     };
-    int tile = blockIdx.x * 4 + wave;
+    int tile = bid * 4 + wave;
     if (tile >= ntiles) return;
     Raw cur[16], nxt[16];
     fetch(tile, cur);
     for (; tile < ntiles; tile += stride) {
-#if !(FB_C1_ABL & 4)
         if (tile + stride < ntiles) fetch(tile + stride, nxt);
-#endif
         int z;                                   // opaque 0: keeps the 48 weight fragments in LDS (re-read per tile)
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));      // instead of hoisted into 192 registers at one wave per SIMD
         const uint4 *wlz = wl + z;
@@ -533,19 +540,12 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             bf16x8 A;
-#if FB_C1_ABL & 2
-            if constexpr (NIB) A = __builtin_bit_cast(bf16x8, make_uint4(cur[c], 0x437F0000u, 0x437Fu, 0u));
-#else
             if constexpr (NIB) A = __builtin_bit_cast(bf16x8, lut[cur[c]]);
-#endif
             else A = u8x8_to_bf16(cur[c]);
 #pragma unroll
             for (int part = 0; part < 3; part++)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), A, acc, 0, 0, 0);
         }
-#if FB_C1_ABL & 1
-        if (acc[0] != 1234.5f) continue;
-#endif
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = quad_max(acc[r]);
         const int Pp = tile * 8 + pp;
@@ -878,11 +878,25 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
     float acc[MAXA + 1];
 #pragma unroll
     for (int a = 0; a <= MAXA; a++) acc[a] = 0.f;
-    for (int jj = lane; jj < H.FC; jj += 64) {
-        const float x = fc1_out(H.hf, H.stot, H.FC, smp, jj, P[H.off.bf1 + jj], H.nks);
+    // a lane takes 4 consecutive units per round (FC % 128 == 0): the nks partial sums and the bias arrive as float4,
+    // all rounds' loads in flight together; the per-unit arithmetic and its order are those of fc1_out
+    for (int j0 = 4 * lane; j0 < H.FC; j0 += 256) {
+        float4 t[FC1_KS];
 #pragma unroll
-        for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x, P[H.off.wq + jj * H.A + a], acc[a]);
-        if (H.dueling) acc[MAXA] = fmaf(x, P[H.off.wv + jj], acc[MAXA]);
+        for (int ks = 0; ks < FC1_KS; ks++)
+            t[ks] = ks < H.nks ? *reinterpret_cast<const float4 *>(H.hf + ((size_t)ks * H.stot + smp) * H.FC + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = *reinterpret_cast<const float4 *>(P + H.off.bf1 + j0);
+        float4 v = t[0];
+#pragma unroll
+        for (int ks = 1; ks < FC1_KS; ks++) { v.x += t[ks].x; v.y += t[ks].y; v.z += t[ks].z; v.w += t[ks].w; }
+        const float x4[4] = {fmaxf(v.x + bv.x, 0.f), fmaxf(v.y + bv.y, 0.f), fmaxf(v.z + bv.z, 0.f), fmaxf(v.w + bv.w, 0.f)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int jj = j0 + e;
+#pragma unroll
+            for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x4[e], P[H.off.wq + jj * H.A + a], acc[a]);
+            if (H.dueling) acc[MAXA] = fmaf(x4[e], P[H.off.wv + jj], acc[MAXA]);
+        }
     }
 #pragma unroll
     for (int a = 0; a <= MAXA; a++)
@@ -1487,9 +1501,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     const bool sp = big && !p.train && p.ns == 1;
     const int t1 = (maxc * 100 + 7) / 8, t23 = (maxc * 25 + 31) / 32;
     const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
+    // stale split weights: refreshed by the leading workgroups of the conv1 launch (or by a launch of their own when
+    // only a later kernel of the plan is requested)
+    int nws = 0;
     if (sp && h->wsp_stale[p.which]) {
-        const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
-        hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, p.sl.s[0].params, h->wsp[p.which], h->FC);
+        if (only < 0 || only == K_CONV1) nws = WS_BLOCKS;
+        else {
+            const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
+            hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, p.sl.s[0].params, h->wsp[p.which], h->FC);
+        }
         h->wsp_stale[p.which] = false;
     }
     FB_K(K_CONV1) {
@@ -1497,8 +1517,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (sp) {
             // persistent: every wave takes `rounds` tiles, about 3 workgroups per CU
             const int rounds = (t1 + 3071) / 3072, gsp = (t1 + 4 * rounds - 1) / (4 * rounds);
-            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit);
-            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit);
+            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp + nws), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
+            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp + nws), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
         } else if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
         else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
