@@ -39,6 +39,20 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // D layout of the 32x32 tile: lane -> column (lane & 31), register r -> row
 __device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// body(r, row) for the 16 accumulator rows of this lane that exist (row < limit).  A whole tile takes the straight-line
+// path: a guard per row would put every store (and the load feeding it) in its own basic block, and hipcc then waits
+// vmcnt(0) before each one -- 16 serialised write round trips at the end of every kernel.
+template <class F>
+__device__ __forceinline__ void for_rows(int base, int limit, int lane, F body) {
+    if (base + 32 <= limit) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) body(r, base + drow(r, lane));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const int row = base + drow(r, lane); if (row < limit) body(r, row); }
+    }
+}
+
 template <int NW>
 __device__ __forceinline__ void reduce_waves(f32x16 &acc, float *red, int wave, int lane) {
     if (wave > 0 && wave < NW) {
@@ -54,6 +68,17 @@ __device__ __forceinline__ void reduce_waves(f32x16 &acc, float *red, int wave, 
     }
 }
 
+// Loads are never placed under a branch: hipcc waits vmcnt(0) at the join and the loads of one wave serialise into
+// dependent round trips.  The caller passes a VALID address also for a padding lane; the value is zeroed by a select.
+// pins a loaded value in a register where it stands: without it LLVM sinks a load into the (even wave-uniform) branch
+// that uses it, which brings the vmcnt(0)-per-load behaviour back
+__device__ __forceinline__ void keep(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void keep(int &x) { asm volatile("" : "+v"(x)); }
+
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 // KH MFMAs: A from a contiguous run of KH floats (or zeros), B from a column with stride bstride
 template <int KH>
 __device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
@@ -61,12 +86,13 @@ __device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool
     float a[KH], b[KH];
 #pragma unroll
     for (int q = 0; q < KH / 4; q++) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        const float4 v = reinterpret_cast<const float4 *>(arun)[q];
         a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
     }
 #pragma unroll
     for (int t = 0; t < KH; t++) b[t] = bcol[(size_t)t * bstride];
+#pragma unroll
+    for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
 #pragma unroll
     for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
 }
@@ -78,12 +104,13 @@ __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool
     float a[KH], b[KH];
 #pragma unroll
     for (int q = 0; q < KH / 4; q++) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        const float4 v = reinterpret_cast<const float4 *>(arun)[q];
         a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         const float4 u = reinterpret_cast<const float4 *>(brun)[q];
         b[4 * q] = u.x; b[4 * q + 1] = u.y; b[4 * q + 2] = u.z; b[4 * q + 3] = u.w;
     }
+#pragma unroll
+    for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
 #pragma unroll
     for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
 }
@@ -100,18 +127,14 @@ __global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__re
     const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
     const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
     const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
-    const float *arun = p1 + (((size_t)(s.s_off + b) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
+    const float *arun = p1 + (((size_t)(s.s_off + (ok ? b : 0)) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
     const float *bcol = s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j;
     f32x16 acc = {0};
     mma_run_col<32>(arun, ok, bcol, 64, acc);
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
         const float bias = s.params[OFF_B2 + n0 + j];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
-        }
+        for_rows(tile * 32, M, lane, [&](int r, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
     }
 }
 
@@ -126,18 +149,14 @@ __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__re
     const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
     const int iy = oy + ky - 1, ix = ox + kx - 1;
     const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
-    const float *arun = h2 + ((size_t)(s.s_off + b) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
+    const float *arun = h2 + ((size_t)(s.s_off + (ok ? b : 0)) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
     const float *bcol = s.params + OFF_W3 + ((size_t)(wave * 64) + 32 * hl) * 64 + n0 + j;
     f32x16 acc = {0};
     mma_run_col<32>(arun, ok, bcol, 64, acc);
     reduce_waves<9>(acc, red, wave, lane);
     if (wave == 0) {
         const float bias = s.params[OFF_B3 + n0 + j];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
-        }
+        for_rows(tile * 32, M, lane, [&](int r, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
     }
 }
 
@@ -245,14 +264,13 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
             const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;         // even: the pixel pair is inside or outside together
             const bool ok = rowok && ix >= 0 && ix < 80;
             bf16x8 A;
+            const int ixc = ok ? ix : 0;                         // a valid address for the padding taps too; zeroed by a select
             if (NIB) {
-                unsigned idx = 0;                                // entry 0 = all zero = the SAME padding
-                if (ok) idx = row[ix >> 1];
-                A = __builtin_bit_cast(bf16x8, lut[idx]);
+                const unsigned idx = row[ixc >> 1];
+                A = __builtin_bit_cast(bf16x8, lut[ok ? idx : 0u]);      // entry 0 = all zero = the SAME padding
             } else {
-                uint2 v = make_uint2(0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint2 *>(row + (size_t)ix * 4);
-                A = u8x8_to_bf16(v);
+                const uint2 v = *reinterpret_cast<const uint2 *>(row + (size_t)ixc * 4);
+                A = u8x8_to_bf16(make_uint2(ok ? v.x : 0u, ok ? v.y : 0u));
             }
 #pragma unroll
             for (int part = 0; part < 3; part++) {
@@ -291,8 +309,7 @@ __device__ __forceinline__ void load_frag(Frag<KH> &f, const float *__restrict__
                                           int bstride) {
 #pragma unroll
     for (int q = 0; q < KH / 4; q++) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = reinterpret_cast<const float4 *>(arun)[q];
+        const float4 v = sel4(ok, reinterpret_cast<const float4 *>(arun)[q]);
         f.a[4 * q] = v.x; f.a[4 * q + 1] = v.y; f.a[4 * q + 2] = v.z; f.a[4 * q + 3] = v.w;
     }
 #pragma unroll
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(256) void conv2_big_kernel(Slices sl, const float *
         const int ky = c >> 1, kx = 2 * (c & 1) + hl;
         const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
         const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
-        const float *arun = p1 + (((size_t)(s.s_off + b) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
+        const float *arun = p1 + (((size_t)(s.s_off + (ok ? b : 0)) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
         load_frag<32>(f, arun, ok, s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j, 64);
     };
     f32x16 acc = {0};
@@ -329,11 +346,7 @@ __global__ __launch_bounds__(256) void conv2_big_kernel(Slices sl, const float *
         mma_frag<32>(f1, acc);
     }
     const float bias = s.params[OFF_B2 + n0 + j];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int mr = tile * 32 + drow(r, lane);
-        if (mr < M) h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
-    }
+    for_rows(tile * 32, M, lane, [&](int r, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
 }
 
 __global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *
         const int ky = cell / 3, kx = cell - ky * 3;
         const int iy = oy + ky - 1, ix = ox + kx - 1;
         const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
-        const float *arun = h2 + ((size_t)(s.s_off + b) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
+        const float *arun = h2 + ((size_t)(s.s_off + (ok ? b : 0)) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
         load_frag<32>(f, arun, ok, s.params + OFF_W3 + ((size_t)(cell * 64) + 32 * hl) * 64 + n0 + j, 64);
     };
     f32x16 acc = {0};
@@ -361,11 +374,7 @@ __global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *
     }
     mma_frag<32>(f0, acc);
     const float bias = s.params[OFF_B3 + n0 + j];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int mr = tile * 32 + drow(r, lane);
-        if (mr < M) h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f);
-    }
+    for_rows(tile * 32, M, lane, [&](int r, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
 }
 
 // fc1 1600xFC: the K = 1600 reduction is split over FC1_KS = 5 workgroups x 8 waves x 40 k, so every wave
@@ -391,11 +400,7 @@ __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__rest
     mma_run_col<20>(arun, ok, bcol, FC, acc);
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
-        }
+        for_rows(tile * 32, M, lane, [&](int r, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r]; });
     }
 }
 
@@ -425,11 +430,7 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
         if (c + 2 < 20) load_frag<20>(f0, arun + 20 * (c + 2), ok, bcol + (size_t)20 * (c + 2) * FC, FC);
         mma_frag<20>(f1, acc);
     }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int mr = tile * 32 + drow(r, lane);
-        if (mr < M) hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r];
-    }
+    for_rows(tile * 32, M, lane, [&](int r, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r]; });
 }
 
 // ---- split-bf16 inference path (forward only, >= 256 states: the acting path).
@@ -842,18 +843,17 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
 #undef FB_STEP
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = m0 + wave * 32 + drow(r, lane);
-            if (mr < a.M) a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = acc[ct][r];
-        }
+        for_rows(m0 + wave * 32, a.M, lane, [&](int r, int mr) { a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = acc[ct][r]; });
 }
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
 __device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot, int FC, int smp, int jj, float bias, int nks) {
     float v = hfp[(size_t)smp * FC + jj], t[FC1_KS];
 #pragma unroll
-    for (int ks = 1; ks < FC1_KS; ks++) t[ks] = ks < nks ? hfp[((size_t)ks * stot + smp) * FC + jj] : 0.f;   // loads in flight together
+    for (int ks = 1; ks < FC1_KS; ks++) {                        // loads in flight together, none under a branch
+        const float x = hfp[((size_t)(ks < nks ? ks : 0) * stot + smp) * FC + jj];
+        t[ks] = ks < nks ? x : 0.f;
+    }
 #pragma unroll
     for (int ks = 1; ks < FC1_KS; ks++) v += t[ks];              // fixed order; + 0.f is exact
     return fmaxf(v + bias, 0.f);
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
         float4 t[FC1_KS];
 #pragma unroll
         for (int ks = 0; ks < FC1_KS; ks++)
-            t[ks] = ks < H.nks ? *reinterpret_cast<const float4 *>(H.hf + ((size_t)ks * H.stot + smp) * H.FC + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t[ks] = sel4(ks < H.nks, *reinterpret_cast<const float4 *>(H.hf + ((size_t)(ks < H.nks ? ks : 0) * H.stot + smp) * H.FC + j0));
         const float4 bv = *reinterpret_cast<const float4 *>(P + H.off.bf1 + j0);
         float4 v = t[0];
 #pragma unroll
@@ -1043,9 +1043,9 @@ __device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h
 #pragma unroll 4
     for (int t = 0; t < (B + 1) / 2; t++) {
         const int b = 2 * t + hl;
-        float a = 0.f, bb = 0.f;
-        if (b < B) { a = h3[(size_t)b * 1600 + kt * 32 + i]; bb = dhf[(size_t)b * FC + nt * 32 + j]; }
-        acc = mfma(a, bb, acc);
+        const int bc = b < B ? b : 0;
+        const float a = h3[(size_t)bc * 1600 + kt * 32 + i], bb = dhf[(size_t)bc * FC + nt * 32 + j];
+        acc = mfma(b < B ? a : 0.f, b < B ? bb : 0.f, acc);
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + j] = acc[r];
@@ -1067,14 +1067,10 @@ __device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__
     for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc);
     reduce_waves<8>(acc, red, wave, lane);
     if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = mt * 32 + drow(r, lane);
-            if (mr < B) {
-                const size_t o = (size_t)mr * 1600 + kt * 32 + j;
-                dh3[o] = h3[o] > 0.f ? acc[r] : 0.f;
-            }
-        }
+        for_rows(mt * 32, B, lane, [&](int r, int mr) {
+            const size_t o = (size_t)mr * 1600 + kt * 32 + j;
+            dh3[o] = h3[o] > 0.f ? acc[r] : 0.f;
+        });
     }
 }
 
@@ -1108,28 +1104,41 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
     const int mend = mbeg + per < M ? mbeg + per : M;
     f32x16 acc = {0};
     for (int c0 = mbeg; c0 < mend; c0 += 32) {
-        float a[16], bb[16];
+        // every load of the chunk is issued unconditionally from a clamped (valid) address -- 48 loads in flight instead
+        // of 48 dependent round trips -- pinned (keep), and only then masked by selects
+        float a[16], bb[16], dv[16], xv[16];
+        int am[16];
+        bool mok[16], in[16];
+        int par[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            const int m = c0 + 2 * t + hl;
-            a[t] = 0.f; bb[t] = 0.f;
-            if (m < mend) {
-                const int b = m / OPIX, rem = m - b * OPIX, oy = rem / G::OW, ox = rem - oy * G::OW;
-                const int iy = oy * G::S + ky - G::P;
-                if (LAYER == 1) {
-                    const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
-                    if (amax[po] == ((oy & 1) * 2 + (ox & 1))) bb[t] = dy[po];       // max_pool routes to the arg max
-                    const int ix = ox * 4 - 2 + (i >> 2);
-                    if (bias_tile) a[t] = i == 0 ? 1.f : 0.f;
-                    else if (iy >= 0 && iy < 80 && ix >= 0 && ix < 80) a[t] = (float)xu8[(((size_t)b * 80 + iy) * 80 + ix) * 4 + (i & 3)];
-                } else {
-                    bb[t] = dy[(size_t)m * G::CO + cot * 32 + j];
-                    const int ix = ox * G::S + kx - G::P;
-                    if (bias_tile) a[t] = i == 0 ? 1.f : 0.f;
-                    else if (iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW)
-                        a[t] = x[(((size_t)b * G::IH + iy) * G::IW + ix) * G::CI + cit * 32 + i];
-                }
+            const int m0 = c0 + 2 * t + hl;
+            mok[t] = m0 < mend;
+            const int m = mok[t] ? m0 : mbeg;
+            const int b = m / OPIX, rem = m - b * OPIX, oy = rem / G::OW, ox = rem - oy * G::OW;
+            const int iy = oy * G::S + ky - G::P;
+            if (LAYER == 1) {
+                const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
+                am[t] = amax[po];
+                dv[t] = dy[po];
+                par[t] = (oy & 1) * 2 + (ox & 1);
+                const int ix = ox * 4 - 2 + (i >> 2);
+                in[t] = iy >= 0 && iy < 80 && ix >= 0 && ix < 80;
+                xv[t] = (float)xu8[(((size_t)b * 80 + (in[t] ? iy : 0)) * 80 + (in[t] ? ix : 0)) * 4 + (i & 3)];
+            } else {
+                am[t] = 0; par[t] = 0;
+                dv[t] = dy[(size_t)m * G::CO + cot * 32 + j];
+                const int ix = ox * G::S + kx - G::P;
+                in[t] = iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
+                xv[t] = x[(((size_t)b * G::IH + (in[t] ? iy : 0)) * G::IW + (in[t] ? ix : 0)) * G::CI + cit * 32 + i];
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) { keep(dv[t]); keep(xv[t]); if (LAYER == 1) keep(am[t]); }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            bb[t] = mok[t] && am[t] == par[t] ? dv[t] : 0.f;                         // max_pool routes to the arg max
+            a[t] = bias_tile ? (mok[t] && i == 0 ? 1.f : 0.f) : (mok[t] && in[t] ? xv[t] : 0.f);
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = mfma(a[t], bb[t], acc);
@@ -1158,17 +1167,13 @@ __device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *
     const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, iy = rem / 5, ix = rem - iy * 5;
     const int oy = iy + 1 - ky, ox = ix + 1 - kx;
     const bool ok = m < M && oy >= 0 && oy < 5 && ox >= 0 && ox < 5;
-    const float *arun = dh3 + ((size_t)b * 25 + (ok ? oy * 5 + ox : 0)) * 64 + 32 * hl;
+    const float *arun = dh3 + ((size_t)(ok ? b : 0) * 25 + (ok ? oy * 5 + ox : 0)) * 64 + 32 * hl;
     const float *brun = params + OFF_W3 + ((size_t)(wave * 64) + c0 + j) * 64 + 32 * hl;
     f32x16 acc = {0};
     mma_run_run<32>(arun, ok, brun, acc);
     reduce_waves<9>(acc, red, wave, lane);
     if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? acc[r] : 0.f; }
-        }
+        for_rows(tile * 32, M, lane, [&](int r, int mr) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? acc[r] : 0.f; });
     }
 }
 
@@ -1186,21 +1191,17 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
     const int ty = iy + 1 - ky, tx = ix + 1 - kx;                 // even by construction
     const bool ok = wave < 4 && m < M && ty >= 0 && tx >= 0 && (ty >> 1) < 5 && (tx >> 1) < 5;   // waves 4..7 of a merged launch idle
     const int cell = (ky * 4 + kx) & 15;
-    const float *arun = dh2 + ((size_t)b * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
+    const float *arun = dh2 + ((size_t)(ok ? b : 0) * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
     const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
     f32x16 acc = {0};
     if (wave < 4) mma_run_run<32>(arun, ok, brun, acc);
     reduce_waves<4>(acc, red, wave, lane);
     if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mr = tile * 32 + drow(r, lane);
-            if (mr < M) {
-                const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
-                const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
-                dp1[o] = p1[o] > 0.f ? acc[r] : 0.f;
-            }
-        }
+        for_rows(tile * 32, M, lane, [&](int r, int mr) {
+            const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
+            const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
+            dp1[o] = p1[o] > 0.f ? acc[r] : 0.f;
+        });
     }
 }
 
