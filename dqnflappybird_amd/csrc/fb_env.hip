@@ -120,7 +120,22 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                                                   int32_t *__restrict__ score) {
     __shared__ EnvLds L;
     __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
+    // everything the first env of this workgroup needs from global memory is requested BEFORE the sprite tables are
+    // waited for: state, action and the old nibble words travel together with the 25 KB of tables (one round trip
+    // instead of three dependent ones)
+    int32_t st0[16];
+    int act0 = 0;
+    uint32_t nib0[2] = {0u, 0u};
     {
+        const int env = blockIdx.x;                 // < n_envs: the grid never exceeds the env count
+#pragma unroll
+        for (int i = 0; i < 16; i++) st0[i] = p.state[(size_t)env * 16 + i];
+        if (STEP) act0 = actions[env];
+        if (STEP && p.nib) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nib + (size_t)env * 3200);
+            nib0[0] = src[threadIdx.x];
+            nib0[1] = src[threadIdx.x + ENV_THREADS < 800 ? threadIdx.x + ENV_THREADS : 0];
+        }
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
         for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += ENV_THREADS) dst[i] = src[i];
@@ -129,14 +144,19 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     for (int env = blockIdx.x; env < p.n_envs; env += gridDim.x) {
+        const bool first = env == (int)blockIdx.x;
         int32_t st[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = p.state[(size_t)env * 16 + i];
+        for (int i = 0; i < 16; i++) st[i] = st0[i];
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) st[i] = p.state[(size_t)env * 16 + i];
+        }
 
         float rew = 0.1f;
         int term = 0, score_ret = st[5], bad = 0;
         if (STEP) {
-            const int act = actions[env];
+            const int act = first ? act0 : (int)actions[env];
             bad = act > 1;                                         // ValueError('Multiple input actions!'), :99-100
             if (!bad) {
                 int flapped = 0;
@@ -269,7 +289,9 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                 uint32_t top = 0;
 #pragma unroll
                 for (int m = 0; m < 8; m++) top |= ((t >> m) & 1u) << (4 * m + 3);
-                dst[w] = STEP ? (((dst[w] >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
+                uint32_t old = 0u;
+                if (STEP) old = first ? nib0[w >= ENV_THREADS ? 1 : 0] : dst[w];
+                dst[w] = STEP ? (((old >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
             }
         }
         if (frames) {

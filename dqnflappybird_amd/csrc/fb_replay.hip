@@ -187,8 +187,11 @@ __device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
 __device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k, long long setsize, long long steps,
                                                     long long *__restrict__ out, uint32_t *mt, int *pool) {
     const int lane = threadIdx.x;
+    // the whole block is fetched beside the cursor (one round trip; a window that depends on the cursor would be two);
+    // it is written back only when this call regenerated it -- otherwise the cursor alone
     for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
     uint32_t idx = P.mt->idx;
+    bool regenerated = false;
     const long long total = steps * P.n_envs;
     const long long n = total < P.cap ? total : P.cap;
     if (k > n || k > MAXB) {
@@ -202,7 +205,7 @@ __device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k
         const int shift = __builtin_clz((uint32_t)n);   // 32 - n.bit_length()
         int i = 0;
         while (i < k) {
-            if (idx >= 624) { mt_regen(mt, lane); idx = 0; }
+            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
             const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
             const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
             unsigned long long mask = __ballot(lane < take && w < (uint32_t)n);
@@ -228,7 +231,7 @@ __device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k
             const int nbits = 32 - __builtin_clz(m);
             uint32_t r;
             do {                                        // _randbelow_with_getrandbits
-                if (idx >= 624) { mt_regen(mt, lane); idx = 0; }
+                if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
                 r = mt_temper(mt[idx++]) >> (32 - nbits);
             } while (r >= m);
             const long long res = pool[r];
@@ -240,7 +243,7 @@ __device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
-    for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];
+    if (regenerated) for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];       // the block only changes when it is regenerated
     if (lane == 0) P.mt->idx = idx;
 }
 
