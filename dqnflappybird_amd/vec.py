@@ -167,9 +167,11 @@ class VecReplay:
         L.check(L.lib().fb_replay_current_state(self.h, L.ptr(out), L.current_stream()), "fb_replay_current_state")
         return out
 
-    def sample(self, batch, uniforms=None):
-        """-> idx int64[B] (deque positions, or SumTree indices for PER), isw float64[B] or None."""
-        idx = self._get(f"idx{batch}", (batch,), torch.int64)
+    def sample(self, batch, uniforms=None, out=None):
+        """-> idx int64[B] (deque positions, or SumTree indices for PER), isw float64[B] or None.
+        `out`: an int64[B] device tensor to receive the indices (default: a buffer reused by every call)."""
+        idx = self._get(f"idx{batch}", (batch,), torch.int64) if out is None else out
+        _dev_check(idx)
         isw = self._get(f"isw{batch}", (batch,), torch.float64) if self.prioritized else None
         _dev_check(uniforms)
         L.check(L.lib().fb_replay_sample(self.h, batch, L.ptr(uniforms), L.ptr(idx), L.ptr(isw), L.current_stream()),
