@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -135,6 +137,22 @@ def main():
     acts = (torch.rand(N_ENVS, device="cuda") < 0.1).to(torch.uint8)
     dt_env = timed(lambda i: env.frame_step(acts, want_u8=False), args.steps)
     env_only = world * N_ENVS * args.steps / dt_env
+
+    env_by_n = {str(N_ENVS): round(env_only, 1)}
+    if rank == 0 and not args.no_kernel_legs:                # env-only at N = 4096 and 32768 as well
+        for n_big in (4096, 32768):
+            eb = VecGameState(n_big, seed=seed)
+            eb.observe()
+            ab = (torch.rand(n_big, device="cuda") < 0.1).to(torch.uint8)
+            for _ in range(20):
+                eb.frame_step(ab, want_u8=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                eb.frame_step(ab, want_u8=False)
+            torch.cuda.synchronize()
+            env_by_n[str(n_big)] = round(n_big * 100 / (time.perf_counter() - t0), 1)
+            del eb
 
     # ---------------------------------------------------------------- leg C: train only (sample -> gather -> train)
     graph_used = False
@@ -294,6 +312,14 @@ def main():
                "sample": f"oracle single-env loop of FlappyBirdDQN.py:72-76 (batch-1 act, full render + preprocess, "
                          f"store, random.sample(32), train): {res['env_steps']} env steps incl. {res['grad_steps']} "
                          f"train steps in {res['seconds']:.1f} s, fp64-accumulating scalar C, 1 thread, no 30 FPS cap"}
+        # Memory.sample restated faithfully: get_min_prob (a min over all filled leaves) inside the per-sample loop
+        # (BrainPrioritizedReplyDQN.py:70-71,141), capacity 50 000, full memory
+        mem = orc.Memory(50000)
+        mem.store(50000)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            mem.sample(32, u=np.full(32, 0.5))
+        cpu["per_sample_ms_faithful"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
         # (ii) all host cores: the reference has ONE env and ONE session, so "all cores" = that many independent
         # replicas of the same loop (one per core, no shared state); the 30 FPS cap of the reference (tick(30),
         # wrapped_flappy_bird.py:179) bounds each replica at 30 env-steps/s and 30 grad-steps/s analytically.
@@ -314,7 +340,7 @@ def main():
             "value": round(env_steps_per_s, 1), "unit": "env-steps/s",
             "grad_steps_per_sec": round(grad_steps_per_s, 1),
             "grad_steps_per_sec_eager": round(grad_steps_eager, 1),
-            "env_only_steps_per_sec": round(env_only, 1),
+            "env_only_steps_per_sec": round(env_only, 1), "env_only_steps_per_sec_by_n_envs": env_by_n,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",

@@ -1333,7 +1333,7 @@ __global__ void init_params_kernel(float *__restrict__ p, long long n, NetOff of
 }  // namespace
 
 #ifndef FB_ADAM_GRID
-#define FB_ADAM_GRID 512
+#define FB_ADAM_GRID 1024
 #endif
 constexpr int ADAM_GRID = FB_ADAM_GRID;
 
