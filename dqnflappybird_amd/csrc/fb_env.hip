@@ -25,6 +25,7 @@ constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H
 constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
 constexpr int ENV_THREADS = 512;  // 8 waves: the 80 output rows of an env are rendered 8 at a time
 constexpr int GROUND_C0 = 63;    // first observation column whose taps all lie in the ground sprite
+constexpr int PIPE_DX = PIPE_W + 1, BIRD_ROWS = 12;
 constexpr size_t BLOB_BYTES = 8 + 4 + 1024 + PIPE_H * PIPE_W + 3 * BIRD_H * BIRD_W + BASE_H * BASE_W;
 
 struct alignas(16) EnvLds {      // staged into LDS by every workgroup
@@ -34,6 +35,14 @@ struct alignas(16) EnvLds {      // staged into LDS by every workgroup
     uint32_t ground_bits[12 * OBS];      // [basex / -4][r] bit (c - 63)
     int16_t xo[OBS], xb0[OBS], xb1[OBS]; // game-x taps per output row r (cv vertical pass)
     int16_t yo[OBS], ya0[OBS], ya1[OBS]; // game-y taps per output column c (cv horizontal pass)
+    // pre-rendered rows (fb_env_create): the 63 non-ground columns of an observation row that meets a pipe pair
+    // with gap index g at x offset dx - 1 = xo[r] - pipe_x, for the row phase r % 5 (the taps repeat every 5 rows:
+    // 3.6 * 5 = 18), and the up to 8 columns a bird at y % 32 lights in bird row rb (its x is fixed; the column
+    // pattern repeats every 32 source pixels = 5 columns)
+    unsigned long long pipe_mask[8 * PIPE_DX * 5];
+    uint8_t bird_pat[3 * BIRD_ROWS * 32];
+    uint8_t bird_cb[32];                 // first column of that pattern for y % 32
+    int16_t bird_r0, bird_nr, pad_[6];   // observation rows whose x taps touch the bird
 };
 static_assert(sizeof(EnvLds) % 16 == 0, "EnvLds must be a multiple of 16 bytes");
 
@@ -120,6 +129,9 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                                                   int32_t *__restrict__ score) {
     __shared__ EnvLds L;
     __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
+    __shared__ unsigned long long rowm[OBS];        // columns 0..62 of every output row
+    __shared__ int slow_rows[OBS];
+    __shared__ int nslow;
     // everything the first env of this workgroup needs from global memory is requested BEFORE the sprite tables are
     // waited for: state, action and the old nibble words travel together with the 25 KB of tables (one round trip
     // instead of three dependent ones)
@@ -219,17 +231,44 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         // packed words in LDS (a row straddles two or three words), then written out coalesced.
         const int gidx = (-st[4]) >> 2;                           // basex in {0,-4,..,-44}
         for (int w = threadIdx.x; w < 100; w += ENV_THREADS) fw[w] = 0ull;
+        if (threadIdx.x == 0) nslow = 0;
         __syncthreads();
         const int py = __builtin_amdgcn_readfirstlane(st[0]), pidx = __builtin_amdgcn_readfirstlane(st[2]);
         const int npipes = __builtin_amdgcn_readfirstlane(st[6]);
-        int pxs[3], gys[3];
+        int pxs[3], gys[3], gis[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) { pxs[i] = __builtin_amdgcn_readfirstlane(st[7 + i]); gys[i] = gap_y(__builtin_amdgcn_readfirstlane(st[10 + i])); }
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        for (int r = wv; r < OBS; r += ENV_THREADS / 64) {
+        for (int i = 0; i < 3; i++) {
+            pxs[i] = __builtin_amdgcn_readfirstlane(st[7 + i]); gis[i] = __builtin_amdgcn_readfirstlane(st[10 + i]);
+            gys[i] = gap_y(gis[i]);
+        }
+        // ---- observation.  Thread r < 80 owns output row r.  A row that meets only pipes, or only the bird, is a table
+        // lookup (EnvLds::pipe_mask / bird_pat: the same four-tap arithmetic, done once on the host for every sprite
+        // offset and tap phase); a row whose taps touch the bird AND a pipe goes to the per-pixel path below, which
+        // resolves every tap against the sprite on top (at most the 9 bird rows, only while a pipe passes the bird).
+        if (threadIdx.x < OBS) {
+            const int r = threadIdx.x, x0 = L.xo[r], ph = r % 5;
+            unsigned long long m = 0ull;
+            bool haspipe = false;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int dx = x0 - pxs[i] + 1;
+                if (i < npipes && dx >= 0 && dx < PIPE_DX) { haspipe = true; m |= L.pipe_mask[(gis[i] * PIPE_DX + dx) * 5 + ph]; }
+            }
+            const int rb = r - L.bird_r0;
+            const bool hasbird = rb >= 0 && rb < L.bird_nr;
+            if (hasbird && (haspipe || py < 0 || py >= 384)) slow_rows[atomicAdd(&nslow, 1)] = r;   // (y out of the table's range: only via set_state)
+            else if (hasbird) {
+                const int rmd = py & 31;
+                m |= ((unsigned long long)L.bird_pat[(pidx * BIRD_ROWS + rb) * 32 + rmd] << (L.bird_cb[rmd] + 5 * (py >> 5))) & 0x7FFFFFFFFFFFFFFFull;
+            }
+            rowm[r] = m;
+        }
+        __syncthreads();
+        const int wv = __builtin_amdgcn_readfirstlane(wave), ns = nslow;
+        for (int q = wv; q < ns; q += ENV_THREADS / 64) {
+            const int r = slow_rows[q];
             const int x0 = L.xo[r];
             int bcol[2], pcol[2], pgy[2];                         // per x tap: bird column / pipe column (or -1) and its gap
-            bool any = false;
 #pragma unroll
             for (int tx = 0; tx < 2; tx++) {
                 const int x = x0 + tx;
@@ -240,42 +279,42 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                     const int col = x - pxs[i];
                     if (i < npipes && col >= 0 && col < PIPE_W) { pcol[tx] = col; pgy[tx] = gys[i]; }
                 }
-                any |= bcol[tx] >= 0 || pcol[tx] >= 0;
             }
-            unsigned long long m = 0ull;
-            if (any) {
-                const int c = lane < GROUND_C0 ? lane : 0;
-                const int y0 = L.yo[c];
-                int idx[2][2];
+            const int c = lane < GROUND_C0 ? lane : 0;
+            const int y0 = L.yo[c];
+            int idx[2][2];
 #pragma unroll
-                for (int tx = 0; tx < 2; tx++)
+            for (int tx = 0; tx < 2; tx++)
 #pragma unroll
-                    for (int ty = 0; ty < 2; ty++) {
-                        const int y = y0 + ty, by = y - py;
-                        int v = 0;
-                        if (bcol[tx] >= 0 && by >= 0 && by < BIRD_H) v = L.bird[(pidx * BIRD_H + by) * BIRD_W + bcol[tx]];
-                        if (!v && pcol[tx] >= 0) {
-                            if (y < pgy[tx]) v = L.pipe[(pgy[tx] - 1 - y) * PIPE_W + (PIPE_W - 1 - pcol[tx])];
-                            else if (y >= pgy[tx] + GAP) v = L.pipe[(y - pgy[tx] - GAP) * PIPE_W + pcol[tx]];
-                        }
-                        idx[tx][ty] = v;
+                for (int ty = 0; ty < 2; ty++) {
+                    const int y = y0 + ty, by = y - py;
+                    int v = 0;
+                    if (bcol[tx] >= 0 && by >= 0 && by < BIRD_H) v = L.bird[(pidx * BIRD_H + by) * BIRD_W + bcol[tx]];
+                    if (!v && pcol[tx] >= 0) {
+                        if (y < pgy[tx]) v = L.pipe[(pgy[tx] - 1 - y) * PIPE_W + (PIPE_W - 1 - pcol[tx])];
+                        else if (y >= pgy[tx] + GAP) v = L.pipe[(y - pgy[tx] - GAP) * PIPE_W + pcol[tx]];
                     }
-                int bit = 0;
-                if (idx[0][0] | idx[0][1] | idx[1][0] | idx[1][1])
-                    bit = resize_gray_bit(L.pal[idx[0][0]], L.pal[idx[0][1]], L.pal[idx[1][0]], L.pal[idx[1][1]], L.ya0[c],
-                                          L.ya1[c], L.xb0[r], L.xb1[r]);
-                m = __ballot(bit && lane < GROUND_C0);
-            }
-            if (lane == 0) {
-                const unsigned long long g = L.ground_bits[gidx * OBS + r];       // 17 bits, columns 63..79
-                const int p0 = r * OBS, w0 = p0 >> 6, sh = p0 & 63;               // row = bits [p0, p0 + 80)
-                const unsigned long long lo = m | (g << GROUND_C0);               // columns 0..63 (bit 63 = column 63)
-                const unsigned long long hi = g >> 1;                             // columns 64..79
-                atomicOr(&fw[w0], lo << sh);
-                if (sh) atomicOr(&fw[w0 + 1], (lo >> (64 - sh)) | (hi << sh));
-                else atomicOr(&fw[w0 + 1], hi);
-                if (sh > 48) atomicOr(&fw[w0 + 2], hi >> (64 - sh));
-            }
+                    idx[tx][ty] = v;
+                }
+            int bit = 0;
+            if (idx[0][0] | idx[0][1] | idx[1][0] | idx[1][1])
+                bit = resize_gray_bit(L.pal[idx[0][0]], L.pal[idx[0][1]], L.pal[idx[1][0]], L.pal[idx[1][1]], L.ya0[c],
+                                      L.ya1[c], L.xb0[r], L.xb1[r]);
+            const unsigned long long m = __ballot(bit && lane < GROUND_C0);
+            if (lane == 0) rowm[r] = m;
+        }
+        __syncthreads();
+        // a row's 80 bits (63 rendered + 17 ground) are OR-ed into the frame's 100 packed words (a row straddles two or three)
+        if (threadIdx.x < OBS) {
+            const int r = threadIdx.x;
+            const unsigned long long g = L.ground_bits[gidx * OBS + r];           // 17 bits, columns 63..79
+            const int p0 = r * OBS, w0 = p0 >> 6, sh = p0 & 63;                   // row = bits [p0, p0 + 80)
+            const unsigned long long lo = rowm[r] | (g << GROUND_C0);             // columns 0..63 (bit 63 = column 63)
+            const unsigned long long hi = g >> 1;                                 // columns 64..79
+            atomicOr(&fw[w0], lo << sh);
+            if (sh) atomicOr(&fw[w0 + 1], (lo >> (64 - sh)) | (hi << sh));
+            else atomicOr(&fw[w0 + 1], hi);
+            if (sh > 48) atomicOr(&fw[w0 + 2], hi >> (64 - sh));
         }
         __syncthreads();
         if (frame_bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) frame_bits[(size_t)env * 100 + w] = fw[w];
@@ -426,6 +465,63 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
             }
             hc->l.ground_bits[g * OBS + r] = bits;
         }
+    // pre-rendered rows.  The tap tables repeat: 5 rows = 18 source pixels, 5 columns = 32 source pixels.
+    for (int r = 0; r + 5 < OBS; r++)
+        if (hc->l.xo[r + 5] != hc->l.xo[r] + 18 || hc->l.xb0[r + 5] != hc->l.xb0[r] || hc->l.xb1[r + 5] != hc->l.xb1[r] ||
+            hc->l.yo[r + 5] != hc->l.yo[r] + 32 || hc->l.ya0[r + 5] != hc->l.ya0[r] || hc->l.ya1[r + 5] != hc->l.ya1[r]) {
+            delete hc;
+            return fb_set_error(FB_ERR_INVALID, "fb_env_create: tap tables are not 5-periodic");
+        }
+    auto pipe_px = [&](int g, int col, int y) -> int {         // wrapped_flappy_bird.py:165-170, upper pipe rotated by 180
+        if (col < 0 || col >= PIPE_W) return 0;
+        const int gy = 100 + 10 * g;
+        if (y < gy) return hc->l.pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];
+        if (y >= gy + GAP) return hc->l.pipe[(y - gy - GAP) * PIPE_W + col];
+        return 0;
+    };
+    for (int g = 0; g < 8; g++)
+        for (int dx = 0; dx < PIPE_DX; dx++)
+            for (int ph = 0; ph < 5; ph++) {
+                unsigned long long m = 0;
+                for (int c = 0; c < GROUND_C0; c++) {
+                    uint32_t s2[2][2];
+                    for (int tx = 0; tx < 2; tx++)
+                        for (int ty = 0; ty < 2; ty++) s2[tx][ty] = hc->l.pal[pipe_px(g, dx - 1 + tx, hc->l.yo[c] + ty)];
+                    m |= (unsigned long long)host_gray_bit(s2[0][0], s2[0][1], s2[1][0], s2[1][1], hc->l.ya0[c], hc->l.ya1[c],
+                                                           hc->l.xb0[ph], hc->l.xb1[ph]) << c;
+                }
+                hc->l.pipe_mask[(g * PIPE_DX + dx) * 5 + ph] = m;
+            }
+    int br0 = -1, bnr = 0;
+    for (int r = 0; r < OBS; r++)
+        if (hc->l.xo[r] + 1 >= PLAYERX && hc->l.xo[r] < PLAYERX + BIRD_W) { if (br0 < 0) br0 = r; bnr = r - br0 + 1; }
+    if (br0 < 0 || bnr > BIRD_ROWS) { delete hc; return fb_set_error(FB_ERR_INVALID, "fb_env_create: bird row table too small"); }
+    hc->l.bird_r0 = (int16_t)br0; hc->l.bird_nr = (int16_t)bnr;
+    for (int rmd = 0; rmd < 32; rmd++) {
+        int cb = 0;
+        while (cb < OBS - 8 && hc->l.yo[cb] + 1 < rmd) cb++;     // first column with a tap at y >= rmd
+        hc->l.bird_cb[rmd] = (uint8_t)cb;
+        for (int pi = 0; pi < 3; pi++)
+            for (int rb = 0; rb < bnr; rb++) {
+                const int r = br0 + rb;
+                unsigned pat = 0;
+                for (int k = 0; k < 8; k++) {
+                    const int c = cb + k;
+                    uint32_t s2[2][2];
+                    for (int tx = 0; tx < 2; tx++)
+                        for (int ty = 0; ty < 2; ty++) {
+                            const int bx = hc->l.xo[r] + tx - PLAYERX, by = hc->l.yo[c] + ty - rmd;
+                            const int v = bx >= 0 && bx < BIRD_W && by >= 0 && by < BIRD_H ? hc->l.bird[(pi * BIRD_H + by) * BIRD_W + bx] : 0;
+                            s2[tx][ty] = hc->l.pal[v];
+                        }
+                    pat |= (unsigned)host_gray_bit(s2[0][0], s2[0][1], s2[1][0], s2[1][1], hc->l.ya0[c], hc->l.ya1[c], hc->l.xb0[r],
+                                                   hc->l.xb1[r]) << k;
+                }
+                // the pattern must fit its 8 columns: nothing of the bird may reach column cb + 8
+                hc->l.bird_pat[(pi * BIRD_ROWS + rb) * 32 + rmd] = (uint8_t)pat;
+            }
+        if (hc->l.yo[cb + 8] <= rmd + BIRD_H - 1) { delete hc; return fb_set_error(FB_ERR_INVALID, "fb_env_create: bird pattern wider than 8 columns"); }
+    }
     fb_env *h = new fb_env();
     memset(h, 0, sizeof(*h));
     hipError_t e = hipMalloc(&h->d_const, sizeof(EnvConst));
