@@ -53,7 +53,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dqnflappybird_amd import _lib as L
-    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,11 +107,15 @@ def main():
         else:
             net.train_step("dqn", s, a, r, s2, t, want_aux=False)
 
+    # the whole step as one host call (fb_vec_step: act on the nibble states -> env -> store + random.sample ->
+    # gather -> train; the same launches as the separate calls, without the interpreter between them)
+    one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad)
+
     def full_step(step):
-        actions = net.act_nib(nib, eps, seed=seed + rank, step=step)      # currentState never leaves nibble form
-        env.frame_step(actions, want_u8=False)
-        # store + random.sample(32) in one launch (identical indices: the sample depends on the size only)
-        train_on(replay.push_sample(env.frame_bits, actions, env.reward, env.terminal, BATCH))
+        one_step(eps, seed=seed + rank, step=step)
+        if world > 1:
+            dist.all_reduce(grad)                           # sum loss (BrainDQN.py:162) -> plain sum
+            net.apply_adam(grad)
 
     def timed(fn, k, first=0):
         barrier()

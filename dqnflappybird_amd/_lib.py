@@ -71,7 +71,14 @@ SIGNATURES = {
     "fb_qnet_sync_target": [_vp, _vp],
     "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
     "fb_qnet_kernel_name": [_i],
+    "fb_vec_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _i, _d, _vp],
 }
+
+
+class StepBuffers(C.Structure):
+    """fb_step_buffers (include/fbdqn.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("nib", "actions", "frame_bits", "reward", "terminal", "score", "idx", "s", "s2", "a", "t",
+                                           "r", "loss", "flat_grad")]
 
 _lib = None
 

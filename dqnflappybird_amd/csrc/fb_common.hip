@@ -46,3 +46,23 @@ void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int key_length) {
     mt[0] = 0x80000000u;
     s->idx = 624;
 }
+
+// One step of the vectorised loop as a single host call: the five C-ABI calls of FlappyBirdDQN.py:72-76 back to back.
+extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
+                           int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream) {
+    FB_REQUIRE(env && replay && net && b, "fb_vec_step: NULL handle");
+    FB_REQUIRE(b->nib && b->actions && b->frame_bits && b->reward && b->terminal && b->score, "fb_vec_step: NULL env buffer");
+    FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
+    int rc = fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
+    if (rc != FB_OK) return rc;
+    rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
+    if (rc != FB_OK) return rc;
+    if (!train) return fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
+    FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
+    rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
+    if (rc != FB_OK) return rc;
+    rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
+    if (rc != FB_OK) return rc;
+    return fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, nullptr, gamma, b->loss, nullptr, nullptr, b->flat_grad,
+                              stream);
+}

@@ -332,3 +332,38 @@ class QNet:
     def apply_adam(self, flat_grad):
         _dev_check(flat_grad)
         L.check(L.lib().fb_qnet_apply_adam(self.h, L.ptr(flat_grad), L.current_stream()), "fb_qnet_apply_adam")
+
+
+class VecStep:
+    """One whole step of the vectorised loop (FlappyBirdDQN.py:72-76 for N envs, uniform replay) as a single
+    host call, fb_vec_step: getAction -> frame_step -> store + random.sample -> minibatch -> _trainQNetwork.
+    The same C-ABI calls in the same order as the separate VecGameState / VecReplay / QNet methods (identical
+    results); the pointers are bound once, so the interpreter spends one ctypes call per step instead of five."""
+
+    def __init__(self, env, replay, net, batch=32, algo="dqn", gamma=0.99, flat_grad=None):
+        if replay.prioritized or algo == "per":
+            raise ValueError("VecStep is for uniform replay (PER needs the importance weights: use the separate calls)")
+        if getattr(env, "nib", None) is None:
+            raise ValueError("call env.track_state() first: the acting path reads the env kernel's nibble states")
+        _dev_check(flat_grad)
+        self.env, self.replay, self.net = env, replay, net
+        self.batch, self.algo, self.gamma, self.flat_grad = batch, ALGOS[algo], float(gamma), flat_grad
+        dev, B = env.device, batch
+        self.actions = torch.zeros(env.n, dtype=torch.uint8, device=dev)
+        self.idx = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.s = torch.empty((B, 80, 80, 4), dtype=torch.uint8, device=dev)
+        self.s2 = torch.empty((B, 80, 80, 4), dtype=torch.uint8, device=dev)
+        self.a = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.r = torch.empty(B, dtype=torch.float32, device=dev)
+        self.t = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        p = lambda x: None if x is None else x.data_ptr()
+        self.buf = L.StepBuffers(p(env.nib), p(self.actions), p(env.frame_bits), p(env.reward), p(env.terminal), p(env.score),
+                                 p(self.idx), p(self.s), p(self.s2), p(self.a), p(self.t), p(self.r), p(self.loss), p(flat_grad))
+
+    def __call__(self, epsilon, seed=0, step=0, train=True):
+        """-> actions uint8[N] (device); rewards / terminals / scores are the env's tensors, loss is self.loss."""
+        L.check(L.lib().fb_vec_step(self.env.h, self.replay.h, self.net.h, C.byref(self.buf), self.env.n, self.algo, self.batch,
+                                    float(epsilon), int(seed), int(step), int(bool(train)), self.gamma, L.current_stream()),
+                "fb_vec_step")
+        return self.actions

@@ -236,6 +236,27 @@ int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int algo, int batc
                            const float *r, const uint8_t *s2, const uint8_t *t, float *loss, void *stream);
 const char *fb_qnet_kernel_name(int kernel);
 
+/* ------------------------------------------------------------------ one whole step of the vectorised loop
+ * FlappyBirdDQN.py:72-76 for N envs in ONE call (uniform replay): getAction (fb_qnet_act_nib) -> frame_step
+ * (fb_env_step, packed frames) -> store + random.sample (fb_replay_push_sample) -> minibatch (fb_replay_gather)
+ * -> _trainQNetwork (fb_qnet_train_step).  Exactly those calls in that order on `stream`; what it saves is the
+ * host's per-call overhead between launches (the GPU otherwise idles ~15 us per step waiting for the interpreter).
+ * All pointers [dev], caller owned; nib is the buffer given to fb_env_set_nib_buffer.  train = 0 stops after the
+ * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
+ * fb_qnet_apply_adam). */
+typedef struct {
+    uint8_t *nib;                                   /* u8[N,3200] */
+    uint8_t *actions;                               /* u8[N] out */
+    uint64_t *frame_bits;                           /* u64[N,100] out */
+    float *reward; uint8_t *terminal; int32_t *score;   /* [N] out */
+    int64_t *idx;                                   /* i64[B] out */
+    uint8_t *s, *s2, *a, *t; float *r;              /* gathered minibatch: u8[B,80,80,4] x2, u8[B], u8[B], f32[B] */
+    float *loss;                                    /* f32[1] out */
+    float *flat_grad;                               /* f32[n_params] or NULL */
+} fb_step_buffers;
+int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo, int batch,
+                float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,3 +177,38 @@ def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cu
         acts = torch.from_numpy((rng.random(N) < 0.2).astype(np.uint8)).cuda()
         env.frame_step(acts, want_u8=False)
         rep.push(env.frame_bits, acts, env.reward, env.terminal)
+
+
+def test_vec_step_single_call_equals_separate_calls(torch_cuda):
+    """fb_vec_step (one host call per step) == act_nib -> frame_step -> push_sample -> gather -> train_step:
+    same actions, env states, sampled indices and parameters after 40 steps (8 of them in the OBSERVE phase)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    N, B = 256, 32
+
+    def make():
+        env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+        rep.seed(9, "cpython"); net.init_params(3)
+        nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
+        return env, rep, net, nib
+
+    e1, r1, n1, nib1 = make()
+    e2, r2, n2, nib2 = make()
+    one = VecStep(e2, r2, n2, B, "dqn")
+    for step in range(40):
+        train = step >= 8
+        a1 = n1.act_nib(nib1, 0.05, seed=1, step=step)
+        e1.frame_step(a1, want_u8=False)
+        if train:
+            idx = r1.push_sample(e1.frame_bits, a1, e1.reward, e1.terminal, B)
+            s, a, r, s2, t = r1.gather(idx)
+            loss, _, _ = n1.train_step("dqn", s, a, r, s2, t, want_aux=False)
+        else:
+            r1.push(e1.frame_bits, a1, e1.reward, e1.terminal)
+        a2 = one(0.05, seed=1, step=step, train=train)
+        assert torch.equal(a1, a2)
+        if train:
+            assert torch.equal(idx, one.idx) and torch.equal(loss, one.loss)
+    assert (e1.get_state() == e2.get_state()).all()
+    assert torch.equal(n1.store_params(), n2.store_params())
+    assert torch.equal(nib1, nib2)
