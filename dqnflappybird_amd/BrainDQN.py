@@ -13,7 +13,12 @@ plus the Adam slots the reference also saves) and gameTimes / timeStep / epsilon
 reference's order, into "bird-saved-parameters.txt" -- that file is interchangeable with the reference's.
 A new Brain restores both if they exist; like the reference, the replay memory and onlineTimeStep are
 not saved, so a resumed run observes for OBSERVE steps again.
-Not reproduced: TensorBoard graph dump and matplotlib plots.
+Logs (reference :36-56,224-226,233-235,242-324): loss per train step, the q_target batch per train step, score and
+time step of every finished episode and the reward of every step are kept in the reference's five lists, appended
+to the reference's five text files under "./logs_<game><dir_name>" (same names, same space-separated format) at
+every checkpoint, and plotted into the reference's four PNGs at RECORD_STEP.  Keeping them costs one host read of
+the loss and of the 32 targets per train step, which the single-env path (a PCIe round trip per step anyway)
+does like the reference; `record_logs=False` switches it off.  Not reproduced: the TensorBoard graph dump.
 """
 import os
 import pickle
@@ -45,7 +50,7 @@ class BrainDQN:
     INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY = INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY
 
     def __init__(self, actionNum, gameName, backend=None, fc_width=512, verbose=True, seed=None,
-                 save_root="./saved_parameters"):
+                 save_root="./saved_parameters", logs_root="./logs_", record_logs=True):
         self.actionNum = actionNum
         self.gameName = gameName
         if backend is None:
@@ -67,7 +72,13 @@ class BrainDQN:
         self._seed = random.getrandbits(48) if seed is None else seed
         self.save_path = save_root + self.dir_name                      # reference :45
         self.saved_parameters_file_path = self.save_path + self.gameName + '-saved-parameters.txt'
-        self.logs_path = "./logs_" + self.gameName + self.dir_name
+        self.logs_path = logs_root + self.gameName + self.dir_name                 # reference :49
+        self.record_logs = record_logs
+        self.lost_hist_file_path = self.logs_path + 'lost_hist.txt'
+        self.q_target_file_path = self.logs_path + 'q_targets.txt'
+        self.score_every_episode_file_path = self.logs_path + 'score_every_episode.txt'
+        self.time_steps_when_episode_end_file_path = self.logs_path + 'time_steps_when_episode_end.txt'
+        self.reward_every_time_step_file_path = self.logs_path + 'reward_every_time_step.txt'
         self._createQNetwork()
         self._load_saved_parameters()
 
@@ -197,7 +208,67 @@ class BrainDQN:
         idx = self._be.dev(self._sample_indices())
         s, a, r, s2, t = self.replayMemory.gather(idx)
         loss, _, y = self.net.train_step(self.ALGO, s, a, r, s2, t, gamma=self.GAMMA)
+        self._after_train(loss, y)
+
+    def _after_train(self, loss, y):
+        """reference :224-235: keep loss / targets, checkpoint + flush the logs every SAVE_EVERY steps, plots at RECORD_STEP"""
         self.lost = loss
         self._last_q_target = y
+        if self.record_logs:
+            self.lost_hist.append(float(self._be.host(loss).reshape(-1)[0]))
+            self.q_target_list.append([float(v) for v in self._be.host(y).reshape(-1)])
         if self.timeStep % self.SAVE_EVERY == 0:
             self.save_checkpoint()
+            if self.record_logs:
+                self._save_loss_score_timestep_reward_qtarget_to_file()
+        if self.record_logs and self.timeStep in RECORD_STEP:
+            self._record_by_pic()
+
+    # ------------------------------------------------------------------ logs (reference :242-324)
+    def _save_loss_score_timestep_reward_qtarget_to_file(self):
+        """Append the five lists to their files ('value value ... ', one line per file, like the reference) and
+        clear them."""
+        os.makedirs(self.logs_path, exist_ok=True)
+        for path, values in ((self.lost_hist_file_path, self.lost_hist),
+                             (self.score_every_episode_file_path, self.score_every_episode),
+                             (self.time_steps_when_episode_end_file_path, self.time_steps_when_episode_end),
+                             (self.reward_every_time_step_file_path, self.reward_every_time_step),
+                             (self.q_target_file_path, self.q_target_list)):
+            with open(path, 'a') as f:
+                for v in values:
+                    f.write(str(v) + ' ')
+            del values[:]
+
+    def _get_loss_score_timestep_reward_qtarget_from_file(self):
+        def numbers(path, brackets=False):
+            if not os.path.exists(path):
+                return []
+            with open(path) as f:
+                line = f.readline()
+            if brackets:                                              # q_targets.txt holds str(list) entries
+                line = line.replace('[', '').replace(']', '').replace(',', '')
+            return [float(tok) for tok in line.split(' ') if tok]
+        return (numbers(self.lost_hist_file_path), numbers(self.score_every_episode_file_path),
+                numbers(self.time_steps_when_episode_end_file_path), numbers(self.reward_every_time_step_file_path),
+                numbers(self.q_target_file_path, brackets=True))
+
+    def _record_by_pic(self):
+        """The reference's four plots (loss / score per episode / q_target / score over time steps)."""
+        self._save_loss_score_timestep_reward_qtarget_to_file()
+        loss, scores, ends, _, q_target = self._get_loss_score_timestep_reward_qtarget_from_file()
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        for ys, xs, ylabel, xlabel, name in ((loss, None, 'loss', 'time_step', '_lost_hist_total.png'),
+                                             (scores, None, 'score', 'episode', '_scores_episode_total.png'),
+                                             (q_target, None, 'q_target', 'BATCH * time_step', '_q_target_total.png'),
+                                             (scores, ends, 'score', 'time_step', '_scores_time_step_total.png')):
+            plt.figure()
+            if xs is None:
+                plt.plot(ys, '-')
+            else:
+                plt.plot(xs, ys, '-')
+            plt.ylabel(ylabel)
+            plt.xlabel(xlabel)
+            plt.savefig(self.logs_path + str(self.timeStep) + name)
+            plt.close()

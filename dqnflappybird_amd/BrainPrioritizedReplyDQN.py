@@ -172,7 +172,4 @@ class BrainPrioritizedReplyDQN(BrainDQNNature):
         s, a, r, s2, t = self.replayMemory._rep.gather(tree_idx)
         loss, abs_errors, y = self.net.train_step("per", s, a, r, s2, t, isw=isw, gamma=self.GAMMA)
         self.replayMemory.batch_update(tree_idx, abs_errors)
-        self.lost = loss
-        self._last_q_target = y
-        if self.timeStep % self.SAVE_EVERY == 0:                 # reference :320-327
-            self.save_checkpoint()
+        self._after_train(loss, y)                               # reference :316-329

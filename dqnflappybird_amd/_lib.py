@@ -38,6 +38,7 @@ SIGNATURES = {
     "fb_env_render_full": [_vp, _i, _vp, _vp],
     "fb_env_error_count": [_vp, _vp],
     "fb_env_set_nib_buffer": [_vp, _vp],
+    "fb_env_set_stats_buffer": [_vp, _vp],
     "fb_preprocess_rgb": [_vp, _vp, _i, _vp, _vp],
     "fb_replay_create": [_i64, _i, _i, _vp],
     "fb_replay_destroy": [_vp],

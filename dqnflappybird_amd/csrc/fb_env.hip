@@ -60,6 +60,7 @@ struct EnvParams {
     const EnvConst *cst;
     unsigned long long *err_count;
     uint8_t *nib;                        // optional [n_envs][3200]: 2 pixels x last 4 frames per byte (caller owned)
+    unsigned long long *stats;           // optional [4]: episodes ended, sum / max of their scores, pipes passed (caller owned)
 };
 
 // ------------------------------------------------------------------ device helpers
@@ -222,6 +223,10 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                 terminal[env] = (uint8_t)term;
                 score[env] = score_ret;
                 if (bad) atomicAdd(p.err_count, 1ull);
+                if (p.stats) {           // device-side counters behind the reference's GAME_TIMES / score log lines: no host sync per step
+                    if (term) { atomicAdd(&p.stats[0], 1ull); atomicAdd(&p.stats[1], (unsigned long long)score_ret); atomicMax(&p.stats[2], (unsigned long long)score_ret); }
+                    if (rew == 3.0f) atomicAdd(&p.stats[3], 1ull);
+                }
             }
         }
         // ---- observation, one wave per output row r (lane = column c < 63; columns >= 63 come from the ground
@@ -633,6 +638,13 @@ extern "C" int fb_env_set_nib_buffer(fb_env_t h, uint8_t *nib_states) {
     FB_REQUIRE(h, "fb_env_set_nib_buffer: NULL handle");
     FB_CHECK_HIP(hipDeviceSynchronize());
     h->p.nib = nib_states;
+    return FB_OK;
+}
+
+extern "C" int fb_env_set_stats_buffer(fb_env_t h, uint64_t *stats) {
+    FB_REQUIRE(h, "fb_env_set_stats_buffer: NULL handle");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    h->p.stats = reinterpret_cast<unsigned long long *>(stats);
     return FB_OK;
 }
 

@@ -66,6 +66,13 @@ class VecGameState:
         L.check(L.lib().fb_env_set_nib_buffer(self.h, L.ptr(self.nib)), "fb_env_set_nib_buffer")
         return self.nib
 
+    def track_stats(self):
+        """Device-side episode counters (fb_env_set_stats_buffer): returns the int64[4] tensor
+        [episodes ended, sum of their scores, max score, pipes passed]; read it whenever you log."""
+        self.stats = torch.zeros(4, dtype=torch.int64, device=self.device)
+        L.check(L.lib().fb_env_set_stats_buffer(self.h, L.ptr(self.stats)), "fb_env_set_stats_buffer")
+        return self.stats
+
     def observe(self):
         L.check(L.lib().fb_env_observe(self.h, L.ptr(self.frames), L.ptr(self.frame_bits), L.current_stream()),
                 "fb_env_observe")

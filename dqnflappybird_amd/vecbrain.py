@@ -38,7 +38,7 @@ class VecBrain:
         self.nib = self.env.track_state()                    # currentState of every env, maintained by the env kernel
         self.env.observe()
         self.replay.reset(self.env.frame_bits)
-        self.episodes = torch.zeros((), dtype=torch.int64, device="cuda")
+        self.stats = self.env.track_stats()                  # [episodes, score sum, score max, pipes passed], kept by the env kernel
         self.last_loss = None
 
     def train_step(self, idx=None):
@@ -68,7 +68,6 @@ class VecBrain:
             idx = self.replay.push_sample(self.env.frame_bits, actions, reward, terminal, self.batch)
         else:
             self.replay.push(self.env.frame_bits, actions, reward, terminal)
-        self.episodes += terminal.sum()
         if training:
             self.train_step(idx)
         self.timeStep += 1
@@ -79,5 +78,6 @@ class VecBrain:
             self.step()
             if log_every and (i + 1) % log_every == 0:
                 loss = self.last_loss.item() if self.last_loss is not None else float("nan")
-                print(f"TIMESTEP {self.timeStep} / ENVS {self.n} / EPSILON {self.epsilon:.6f} / EPISODES "
-                      f"{int(self.episodes.item())} / LOSS {loss:.6g}", flush=True)
+                ep, ssum, smax, pipes = self.stats.tolist()      # the only host sync of the loop, once per log line
+                print(f"TIMESTEP {self.timeStep} / ENVS {self.n} / EPSILON {self.epsilon:.6f} / GAME_TIMES {ep} / "
+                      f"MEAN_SCORE {ssum / max(ep, 1):.3f} / MAX_SCORE {smax} / PIPES {pipes} / LOSS {loss:.6g}", flush=True)

@@ -92,6 +92,11 @@ int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream);
  * all four frames with the observation (setInitState); a step shifts and appends.  fb_qnet_act_nib consumes it,
  * which removes the currentState expansion from the acting path.  Synchronous. */
 int fb_env_set_nib_buffer(fb_env_t h, uint8_t *nib_states);
+/* Register (or clear with NULL) a caller-owned u64[4] [dev] that every following fb_env_step updates with atomics:
+ * [0] episodes ended (the reference's gameTimes, BrainDQN.py:92), [1] sum and [2] maximum of their scores
+ * (score_every_episode, :94), [3] pipes passed (reward 3 events).  The vectorised loop reads it back whenever it
+ * logs, instead of syncing per step.  The caller zeroes it.  Synchronous. */
+int fb_env_set_stats_buffer(fb_env_t h, uint64_t *stats);
 /* number of invalid actions seen so far (synchronous). */
 int fb_env_error_count(fb_env_t h, int64_t *count_host);
 /* preprocess() of FlappyBirdDQN.py:31-34 (cv2.resize -> BGR2GRAY -> threshold) for frames the caller

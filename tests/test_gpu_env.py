@@ -149,3 +149,23 @@ def test_bad_blob_is_rejected_loudly(torch_cuda):
     h = C.c_void_p()
     rc = L.lib().fb_env_create(4, 0, 0, b"x" * 100, 100, C.byref(h))
     assert rc == -1 and b"sprite blob" in L.lib().fb_last_error()
+
+
+def test_stats_buffer_counts_episodes_and_scores(torch_cuda):
+    """fb_env_set_stats_buffer: [episodes ended, sum / max of their scores, pipes passed] == the same quantities
+    accumulated on the host from the per-step terminal / score / reward outputs."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecGameState
+    env = VecGameState(200, seed=11)
+    stats = env.track_stats()
+    env.observe()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ep = ssum = smax = pipes = 0
+    for _ in range(300):
+        a = (torch.rand(200, device="cuda", generator=g) < 0.08).to(torch.uint8)
+        _, r, t, sc = env.frame_step(a, want_u8=False)
+        tm = t.bool()
+        ep += int(tm.sum()); ssum += int(sc[tm].sum()); pipes += int((r == 3.0).sum())
+        if tm.any():
+            smax = max(smax, int(sc[tm].max()))
+    assert stats.tolist() == [ep, ssum, smax, pipes] and ep > 100 and pipes > 0
