@@ -214,3 +214,26 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda):
     assert (e1.get_state() == e2.get_state()).all()
     assert torch.equal(n1.store_params(), n2.store_params())
     assert torch.equal(nib1, nib2)
+
+
+def test_standalone_dueling_recipe_on_device(torch_cuda, tmp_path, monkeypatch):
+    """the reference's stand-alone BrainDuelingDQN.py loop end to end on the HIP backend: drop-in game module,
+    preprocess kernel, HBM replay, dueling net, checkpoints."""
+    import os
+    from dqnflappybird_amd import BrainDuelingDQN as R
+    monkeypatch.setattr(R, "OBSERVE", 40.)
+    monkeypatch.setattr(R, "SAVER_ITER", 25)
+    monkeypatch.setattr(R, "REPLACE_TARGET_ITER", 10)
+    random.seed(2)
+    handles = R.createNetwork(seed=3)
+    net = handles[0]
+    p0, t0 = net.get_params(0), net.get_params(1)
+    sp = str(tmp_path / "saved") + "/"
+    t, eps, obs = R.trainNetwork(*handles, sess=None, max_steps=60, verbose=False, save_path=sp, save_back_path=str(tmp_path / "back") + "/")
+    assert t == 60 and obs.shape == (80, 80, 4) and set(np.unique(obs)) <= {0, 255}
+    assert sorted(os.listdir(sp)) == ["bird-dqn-25.npz", "bird-dqn-50.npz", "checkpoint"]
+    assert not np.array_equal(net.get_params(0), p0)                       # 19 train steps happened
+    z = np.load(sp + "bird-dqn-50.npz")              # saved when t became 50, before the first sync (iteration t = 50 > OBSERVE)
+    assert np.array_equal(z["target"], t0) and not np.array_equal(net.get_params(1), t0)
+    q = net.q_values(obs)
+    assert q.shape == (2,) and np.isfinite(q).all()
