@@ -169,3 +169,23 @@ def test_stats_buffer_counts_episodes_and_scores(torch_cuda):
         if tm.any():
             smax = max(smax, int(sc[tm].max()))
     assert stats.tolist() == [ep, ssum, smax, pipes] and ep > 100 and pipes > 0
+
+
+def test_env_trajectory_is_independent_of_the_env_count(torch_cuda):
+    """BASELINE's 32 768 envs: env e of a big launch is bit-identical (state, frame, reward, terminal, score) to env e
+    of a small launch with the same seed -- envs own their Philox streams, nothing depends on the grid."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecGameState
+    big, small = VecGameState(32768, seed=21), VecGameState(48, seed=21)
+    big.observe(); small.observe()
+    assert torch.equal(big.frame_bits[:48], small.frame_bits)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for _ in range(120):
+        a = (torch.rand(32768, device="cuda", generator=g) < 0.09).to(torch.uint8)
+        big.frame_step(a, want_u8=False)
+        small.frame_step(a[:48].contiguous(), want_u8=False)
+        assert torch.equal(big.frame_bits[:48], small.frame_bits)
+        assert torch.equal(big.reward[:48], small.reward) and torch.equal(big.terminal[:48], small.terminal)
+        assert torch.equal(big.score[:48], small.score)
+    assert (big.get_state()[:48] == small.get_state()).all()
+    assert int(big.terminal.sum()) >= 0 and big.error_count() == 0

@@ -342,3 +342,51 @@ def test_per_device_pow_close_to_numpy(torch_cuda, golden):
     got = tree[255:].astype(np.float32)
     ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
     assert ulp.max() <= 1
+
+
+def test_full_size_ring_addressing_one_million_slots(torch_cuda):
+    """BASELINE's 1 M-slot replay with 1024 envs, filled past the wrap (1 100 steps = 1 126 400 stores): the gathered
+    (s, a, r, s', t) of sampled positions equal a closed-form transition generator -- a size-independent property of
+    the ring addressing (deque position j <-> g = oldest + j, (step, env) = divmod(g, N), frame window s = t-3..t)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    N, cap, steps = 1024, 1_000_000, 1100
+    rep = VecReplay(cap, N)
+    env_id = torch.arange(N, device="cuda", dtype=torch.int64)
+
+    def bits(step):                                  # frame of (step, env): 100 words, a cheap injective hash
+        w = torch.arange(100, device="cuda", dtype=torch.int64)
+        x = (step * 1315423911 + env_id[:, None] * 2654435761 + w[None, :] * 97 + 12345) % 2147483647
+        return (x * 6364136223846793005 + (x << 17)).contiguous()
+
+    def meta(step):
+        a = ((env_id * 7 + step) % 2).to(torch.uint8)
+        r = ((env_id + 3 * step) % 5).to(torch.float32) * 0.5
+        t = ((env_id * 13 + step) % 11 == 0).to(torch.uint8)
+        return a, r, t
+
+    rep.reset(bits(0))                               # frame index 0 = the initial observation
+    for st in range(1, steps + 1):
+        a, r, t = meta(st)
+        rep.push(bits(st), a, r, t)                  # transition of step st: s = frames st-4..st-1 (clamped at 0), s' = st-3..st
+    assert len(rep) == cap
+    total = steps * N
+    oldest = total - cap
+    rng = np.random.default_rng(0)
+    j = np.concatenate([rng.integers(0, cap, 60), [0, 1, cap - 1, cap - 2, N - 1, N]])
+    idx = torch.from_numpy(j).cuda()
+    s, a, r, s2, t = rep.gather(idx)
+    g = oldest + j
+    stp, env = g // N + 1, g % N                     # transition pushed at step stp by env
+    fb = {int(k): bits(int(k)) for k in set(np.concatenate([np.maximum(stp - 4 + d, 0) for d in range(5)]).tolist())}
+
+    def unpack(step, e):                             # u8[80,80] of the frame (bit p of the 6400-bit row-major image)
+        words = fb[int(step)][int(e)].cpu().numpy().astype(np.uint64)
+        return (np.unpackbits(words.view(np.uint8), bitorder="little").reshape(80, 80) * 255).astype(np.uint8)
+
+    for b in range(len(j)):
+        for f in range(4):
+            assert np.array_equal(s[b, :, :, f].cpu().numpy(), unpack(max(stp[b] - 4 + f, 0), env[b])), (b, f)
+            assert np.array_equal(s2[b, :, :, f].cpu().numpy(), unpack(max(stp[b] - 3 + f, 0), env[b])), (b, f)
+        am, rm, tm = meta(int(stp[b]))
+        assert (int(a[b]), float(r[b]), int(t[b])) == (int(am[env[b]]), float(rm[env[b]]), int(tm[env[b]]))
