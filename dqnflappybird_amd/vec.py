@@ -39,9 +39,12 @@ class VecGameState:
         self.score = torch.empty(self.n, dtype=torch.int32, device=dev)
 
     def __del__(self):
-        if getattr(self, "h", None) and self.h.value:
-            L.lib().fb_env_destroy(self.h)
-            self.h = C.c_void_p()
+        try:                                     # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "h", None) and self.h.value:
+                L.lib().fb_env_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
 
     def reset(self):
         L.check(L.lib().fb_env_reset(self.h, L.current_stream()), "fb_env_reset")
@@ -121,9 +124,12 @@ class VecReplay:
         self._buf = {}
 
     def __del__(self):
-        if getattr(self, "h", None) and self.h.value:
-            L.lib().fb_replay_destroy(self.h)
-            self.h = C.c_void_p()
+        try:                                     # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "h", None) and self.h.value:
+                L.lib().fb_replay_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
 
     def seed(self, seed, rng=None):
         """rng: 'cpython' (random.seed), 'numpy' (np.random.seed) or 'philox'."""
@@ -240,9 +246,12 @@ class QNet:
         self._buf = {}
 
     def __del__(self):
-        if getattr(self, "h", None) and self.h.value:
-            L.lib().fb_qnet_destroy(self.h)
-            self.h = C.c_void_p()
+        try:                                     # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "h", None) and self.h.value:
+                L.lib().fb_qnet_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
 
     def _get(self, name, shape, dtype):
         t = self._buf.get(name)
