@@ -108,14 +108,15 @@ __device__ __forceinline__ uint32_t expand4(uint32_t n0, uint32_t n1, uint32_t n
 }
 
 template <bool CURRENT>
-__global__ __launch_bounds__(256) void gather_kernel(ReplayParams P, int B, const long long *__restrict__ idx,
+__global__ __launch_bounds__(256) void gather_kernel(ReplayParams P, long long steps, int B, const long long *__restrict__ idx,
                                                      uint4 *__restrict__ s, uint4 *__restrict__ s2,
                                                      uint8_t *__restrict__ a, float *__restrict__ r,
                                                      uint8_t *__restrict__ t) {
+    // `steps` (pushes so far) comes by value from the host's mirror: one dependent global round trip less than reading
+    // ReplayDev::steps here
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= (long long)B * 1600) return;
     const int b = (int)(tid / 1600), chunk = (int)(tid - (long long)b * 1600);
-    const long long steps = P.dev->steps;
     long long tt; int e;
     if (CURRENT) { tt = steps; e = b; }
     else {
@@ -746,7 +747,7 @@ extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *str
     ReplayParams &P = h->P;
     const long long threads = (long long)P.n_envs * 1600;
     hipLaunchKernelGGL(gather_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, fb_stream(stream), P,
-                       P.n_envs, (const long long *)nullptr, (uint4 *)states, (uint4 *)nullptr, (uint8_t *)nullptr,
+                       h->host_steps, P.n_envs, (const long long *)nullptr, (uint4 *)states, (uint4 *)nullptr, (uint8_t *)nullptr,
                        (float *)nullptr, (uint8_t *)nullptr);
     FB_LAUNCH_CHECK();
     return FB_OK;
@@ -775,7 +776,7 @@ extern "C" int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, ui
     FB_REQUIRE(batch >= 1 && batch <= (1 << 20), "fb_replay_gather: batch out of range");
     const long long threads = (long long)batch * 1600;
     hipLaunchKernelGGL(gather_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, fb_stream(stream), h->P,
-                       batch, (const long long *)idx, (uint4 *)s, (uint4 *)s2, a, r, t);
+                       h->host_steps, batch, (const long long *)idx, (uint4 *)s, (uint4 *)s2, a, r, t);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
