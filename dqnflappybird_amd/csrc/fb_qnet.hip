@@ -482,6 +482,18 @@ __device__ __forceinline__ float quad_max(float v) {
 // The first `nws` workgroups of the launch do not convolve: they re-split W_conv2 / W_conv3 / W_fc1 for the kernels
 // that follow (wsplit_item; only when the step changed the parameters) -- one launch and its cold start less.
 constexpr int WS_BLOCKS = 64;
+// 4 x 4 transpose inside every quad of lanes: lane l ends with v[c] = (lane c's v[l]).  Two butterfly stages (partners
+// l ^ 1, then l ^ 2), 16 vector instructions.
+__device__ __forceinline__ float dpp_x1(float v) { const int x = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ float dpp_x2(float v) { const int x = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)); }
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int l) {
+    const bool b0 = l & 1, b1 = l & 2;
+    const float r01 = dpp_x1(b0 ? v[0] : v[1]), r23 = dpp_x1(b0 ? v[2] : v[3]);
+    const float x0 = b0 ? r01 : v[0], x1 = b0 ? v[1] : r01, x2 = b0 ? r23 : v[2], x3 = b0 ? v[3] : r23;
+    const float ra = dpp_x2(b1 ? x0 : x2), rb = dpp_x2(b1 ? x1 : x3);
+    v[0] = b1 ? ra : x0; v[1] = b1 ? rb : x1; v[2] = b1 ? x2 : ra; v[3] = b1 ? x3 : rb;
+}
+
 template <bool NIB>
 __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
                                                                      size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int nws) {
@@ -507,9 +519,7 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     typedef typename std::conditional<NIB, unsigned, uint2>::type Raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31, pp = j >> 2, pos = j & 3;
     const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = nblk * 4;
-    float b4[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) b4[e] = s.params[OFF_B1 + 8 * pos + 4 * hl + e];
+    const float bias = s.params[OFF_B1 + j];
     auto fetch = [&](int tile, Raw (&raw)[16]) {
         const int P = tile * 8 + pp, b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
         const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
@@ -545,22 +555,21 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
             else A = u8x8_to_bf16(cur[c]);
 #pragma unroll
             for (int part = 0; part < 3; part++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), A, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = quad_max(acc[r]);
-        const int Pp = tile * 8 + pp;
+        // D[row = 4 * pixel + window position][col = channel]: register r of a lane is window position r & 3 of pooled pixel
+        // 2 * (r >> 2) + hl for channel j, so the 2x2 max-pool is a max over 4 registers; relu(max + bias) (monotone, so equal
+        // to the max of the relu'd values).  The quad transpose then gives lane l of quad q pixel 2 * l + hl, channels 4q..4q+3.
         float o4[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float v = pos == 0 ? acc[e] : pos == 1 ? acc[4 + e] : pos == 2 ? acc[8 + e] : acc[12 + e];
-            o4[e] = fmaxf(v + b4[e], 0.f);
-        }
+        for (int g = 0; g < 4; g++) o4[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias, 0.f);
+        quad_transpose(o4, j & 3);
+        const int Pp = tile * 8 + 2 * (j & 3) + hl;
         uint32_t hi[2], mid[2], lo[2];
         split3x2(o4[0], o4[1], hi[0], mid[0], lo[0]);
         split3x2(o4[2], o4[3], hi[1], mid[1], lo[1]);
         if (Pp < npool) {
-            uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 8 * pos + 4 * hl;
+            uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 4 * (j >> 2);
             *reinterpret_cast<uint2 *>(o) = make_uint2(hi[0], hi[1]);
             if (nsplit == 3) {
                 *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(mid[0], mid[1]);

@@ -5,14 +5,16 @@ import torch
 from dqnflappybird_amd import _lib as L
 from dqnflappybird_amd.vec import QNet
 lib = L.lib()
-R, B = 200, 32
+R = 100
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ALGO = {"dqn": 0, "nature": 1, "double": 2}[sys.argv[2] if len(sys.argv) > 2 else "dqn"]
 net = QNet(max_batch=1024); net.init_params(0)
 s = ((torch.rand((B, 80, 80, 4), device="cuda") < 0.37).to(torch.uint8) * 255).contiguous()
 s2 = ((torch.rand((B, 80, 80, 4), device="cuda") < 0.37).to(torch.uint8) * 255).contiguous()
 a = torch.zeros(B, dtype=torch.uint8, device="cuda"); r = torch.full((B,), 0.1, device="cuda"); t = torch.zeros(B, dtype=torch.uint8, device="cuda")
 loss = torch.zeros(1, device="cuda")
-for _ in range(200):
-    net.train_step("dqn", s, a, r, s2, t, want_aux=False)
+for _ in range(50):
+    net.train_step(ALGO, s, a, r, s2, t, want_aux=False)
 st = L.current_stream()
 out, tot = [], 0.0
 for k in range(64):
@@ -20,7 +22,7 @@ for k in range(64):
     if not name:
         break
     def run():
-        L.check(lib.fb_qnet_profile_kernel(net.h, k, R, 0, B, L.ptr(s), L.ptr(a), L.ptr(r), L.ptr(s2), L.ptr(t), L.ptr(loss), st), "profile")
+        L.check(lib.fb_qnet_profile_kernel(net.h, k, R, ALGO, B, L.ptr(s), L.ptr(a), L.ptr(r), L.ptr(s2), L.ptr(t), L.ptr(loss), st), "profile")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
