@@ -19,6 +19,7 @@ NET_ONLINE, NET_TARGET = 0, 1
 ALGO_DQN, ALGO_NATURE, ALGO_DOUBLE, ALGO_PER = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 PER_EXACT, PER_FAST = 0, 1
+NIB_PITCH, NIB_ROWS, NIB_STRIDE = 44, 84, 3712       # include/fbdqn.h FB_NIB_*
 
 _vp, _i, _i64, _u64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 

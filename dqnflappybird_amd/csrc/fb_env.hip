@@ -59,7 +59,7 @@ struct EnvParams {
     int32_t *state;                      // [n_envs][16]
     const EnvConst *cst;
     unsigned long long *err_count;
-    uint8_t *nib;                        // optional [n_envs][3200]: 2 pixels x last 4 frames per byte (caller owned)
+    uint8_t *nib;                        // optional [n_envs][FB_NIB_STRIDE]: 2 pixels x last 4 frames per byte, SAME-padded (caller owned)
     unsigned long long *stats;           // optional [4]: episodes ended, sum / max of their scores, pipes passed (caller owned)
 };
 
@@ -121,6 +121,9 @@ __device__ __forceinline__ int resize_gray_bit(uint32_t s00, uint32_t s01, uint3
     return gray > 1;
 }
 
+// 32-bit word of the padded nibble image (include/fbdqn.h, FB_NIB_*) that holds the 8 pixels of unpadded word w
+__device__ __forceinline__ int nib_word(int w) { return (w / 10 + 2) * (FB_NIB_PITCH / 4) + 1 + w % 10; }
+
 // ------------------------------------------------------------------ the step kernel
 template <bool STEP>
 __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         for (int i = 0; i < 16; i++) st0[i] = p.state[(size_t)env * 16 + i];
         if (STEP) act0 = actions[env];
         if (STEP && p.nib) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nib + (size_t)env * 3200);
-            nib0[0] = src[threadIdx.x];
-            nib0[1] = src[threadIdx.x + ENV_THREADS < 800 ? threadIdx.x + ENV_THREADS : 0];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nib + (size_t)env * FB_NIB_STRIDE);
+            const int w1 = threadIdx.x + ENV_THREADS < 800 ? threadIdx.x + ENV_THREADS : 0;
+            nib0[0] = src[nib_word(threadIdx.x)];
+            nib0[1] = src[nib_word(w1)];
         }
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
@@ -327,15 +331,22 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
             // the agent's 4-frame stack (BrainDQN.py:68,238-239: newest last, never reset) as one nibble per pixel:
             // bit f of a pixel's nibble = frame f of the stack; a step shifts the nibbles down and puts the new
             // frame on top, the initial observation fills all four frames.  One u32 = 8 pixels.
-            uint32_t *dst = reinterpret_cast<uint32_t *>(p.nib + (size_t)env * 3200);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(p.nib + (size_t)env * FB_NIB_STRIDE);
+            if (!STEP) {                      // the initial observation also (re)writes conv1's zero padding around the image
+                for (int w = threadIdx.x; w < FB_NIB_STRIDE / 4; w += ENV_THREADS) {
+                    const int row = w / (FB_NIB_PITCH / 4), col = w - row * (FB_NIB_PITCH / 4);
+                    if (row < 2 || row >= 82 || col == 0) dst[w] = 0u;
+                }
+            }
             for (int w = threadIdx.x; w < 800; w += ENV_THREADS) {
                 const unsigned t = (unsigned)(fw[w >> 3] >> ((w & 7) * 8)) & 0xFFu;       // the 8 new pixel bits
                 uint32_t top = 0;
 #pragma unroll
                 for (int m = 0; m < 8; m++) top |= ((t >> m) & 1u) << (4 * m + 3);
                 uint32_t old = 0u;
-                if (STEP) old = first ? nib0[w >= ENV_THREADS ? 1 : 0] : dst[w];
-                dst[w] = STEP ? (((old >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
+                const int pw = nib_word(w);
+                if (STEP) old = first ? nib0[w >= ENV_THREADS ? 1 : 0] : dst[pw];
+                dst[pw] = STEP ? (((old >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
             }
         }
         if (frames) {

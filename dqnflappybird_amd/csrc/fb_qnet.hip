@@ -228,7 +228,7 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 // conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2; one wave per tile of 8 pooled pixels x 4
 // window positions (the pool is a max over 4 accumulator registers of one lane), 48 bf16 MFMAs per tile.
 // NIB = false: states are u8[n][80][80][4] (the reference's layout).  NIB = true (acting path): states are
-// the env kernel's running "nibble state" u8[n][80][40]: one byte = 2 horizontally adjacent pixels x the
+// the env kernel's running "nibble state" (SAME-padded, FB_NIB_* in include/fbdqn.h): one byte = 2 horizontally adjacent pixels x the
 // last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
 // bf16x8 operand comes out of a 256-entry LDS table with one ds_read_b128 -- no u8 -> bf16 conversion, and
 // the 25.6 KB/env currentState expansion (its own launch before) disappears.
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
     for (int ky = 0; ky < 8; ky++) {
         const int iy = oy * 4 + ky - 2;
         const bool rowok = P < npool && iy >= 0 && iy < 80;
-        const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * (NIB ? 1 : 8) / 2;
+        const uint8_t *row = NIB ? s.states + (size_t)b * FB_NIB_STRIDE + ((rowok ? iy : 0) + 2) * FB_NIB_PITCH + 4
+                                 : s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * 4;
 #pragma unroll
         for (int kq = 0; kq < 2; kq++) {
             const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;         // even: the pixel pair is inside or outside together
@@ -521,8 +522,19 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = nblk * 4;
     const float bias = s.params[OFF_B1 + j];
     auto fetch = [&](int tile, Raw (&raw)[16]) {
-        const int P = tile * 8 + pp, b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
+        const int P0 = tile * 8 + pp, P = P0 < npool ? P0 : 0;       // rows past the end compute on state 0 and are not stored
+        const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
         const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+        if constexpr (NIB) {
+            // the nibble image carries conv1's SAME padding (FB_NIB_*): every tap is base + ky * pitch + 2 * kq, no bounds
+            // check, no select -- 16 byte loads at immediate offsets from one address
+            const uint8_t *base = s.states + (size_t)b * FB_NIB_STRIDE + (4 * oy) * FB_NIB_PITCH + 3 + 2 * ox + hl;
+#pragma unroll
+            for (int ky = 0; ky < 8; ky++)
+#pragma unroll
+                for (int kq = 0; kq < 2; kq++) raw[ky * 2 + kq] = base[ky * FB_NIB_PITCH + 2 * kq];
+            return;
+        }
 #pragma unroll
         for (int ky = 0; ky < 8; ky++) {
             const int iy = oy * 4 + ky - 2;

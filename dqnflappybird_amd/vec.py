@@ -64,8 +64,9 @@ class VecGameState:
 
     def track_state(self):
         """Keep the agents' 4-frame stacks on the device in nibble form (fb_env_set_nib_buffer); returns the
-        u8[N,3200] tensor that QNet.act_nib consumes.  Call before observe()."""
-        self.nib = torch.zeros((self.n, 3200), dtype=torch.uint8, device=self.device)
+        u8[N, FB_NIB_STRIDE] tensor (conv1's SAME padding included, include/fbdqn.h) that QNet.act_nib consumes.
+        Call before observe()."""
+        self.nib = torch.zeros((self.n, L.NIB_STRIDE), dtype=torch.uint8, device=self.device)
         L.check(L.lib().fb_env_set_nib_buffer(self.h, L.ptr(self.nib)), "fb_env_set_nib_buffer")
         return self.nib
 

@@ -86,11 +86,18 @@ int fb_env_set_state(fb_env_t h, const int32_t *state_host);
 int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len);
 /* pygame.surfarray.array3d of one env: u8[288,512,3] [dev] (debug / parity). */
 int fb_env_render_full(fb_env_t h, int env_id, uint8_t *rgb, void *stream);
-/* Register (or clear with NULL) a caller-owned buffer u8[N][3200] [dev] that every following fb_env_observe /
- * fb_env_step keeps equal to the agent's 4-frame stack (BrainDQN.py:68,238-239) in "nibble" form: byte q of an
- * env = pixels 2q, 2q+1 (row-major 80x80), bit 4*px + f = frame f of the stack (f = 3 newest).  observe fills
- * all four frames with the observation (setInitState); a step shifts and appends.  fb_qnet_act_nib consumes it,
- * which removes the currentState expansion from the acting path.  Synchronous. */
+/* Register (or clear with NULL) a caller-owned buffer u8[N][FB_NIB_STRIDE] [dev] that every following fb_env_observe /
+ * fb_env_step keeps equal to the agent's 4-frame stack (BrainDQN.py:68,238-239) in "nibble" form: one byte = two
+ * horizontally adjacent pixels, bit 4*px + f = frame f of the stack (f = 3 newest).  The image is stored with conv1's
+ * SAME padding around it, so that the acting conv1 reads every tap at a fixed offset from one base address with no
+ * bounds check: FB_NIB_ROWS rows of FB_NIB_PITCH bytes = [4 zero bytes][40 bytes: pixels 0..79 of the row]; image row r
+ * is buffer row r + 2 (two zero rows above, two below; the right-hand padding of a row is the zero prefix of the next),
+ * i.e. pixels (r, 2q), (r, 2q+1) live in byte (r + 2) * FB_NIB_PITCH + 4 + q.  observe zeroes the padding and fills all
+ * four frames with the observation (setInitState); a step shifts and appends.  fb_qnet_act_nib consumes it, which
+ * removes the currentState expansion from the acting path.  Synchronous. */
+#define FB_NIB_PITCH 44
+#define FB_NIB_ROWS 84
+#define FB_NIB_STRIDE 3712      /* 84 * 44 = 3696, + 16 so that the last row's right-hand taps stay inside */
 int fb_env_set_nib_buffer(fb_env_t h, uint8_t *nib_states);
 /* Register (or clear with NULL) a caller-owned u64[4] [dev] that every following fb_env_step updates with atomics:
  * [0] episodes ended (the reference's gameTimes, BrainDQN.py:92), [1] sum and [2] maximum of their scores
@@ -225,7 +232,7 @@ int fb_qnet_act(fb_qnet_t h, const uint8_t *states, int n, float epsilon, uint64
  *   flat_grad NULL : gradients are applied with Adam at once (single GPU)
  *   flat_grad [dev] f32[n_params]: gradients are only written there (data parallel: all-reduce
  *             them, then fb_qnet_apply_adam) */
-/* fb_qnet_act on the env kernel's nibble states u8[n][3200] (fb_env_set_nib_buffer) */
+/* fb_qnet_act on the env kernel's nibble states u8[n][FB_NIB_STRIDE] (fb_env_set_nib_buffer) */
 int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                     uint8_t *actions, float *q, void *stream);
 int fb_qnet_train_step(fb_qnet_t h, int algo, int batch, const uint8_t *s, const uint8_t *a, const float *r,
@@ -250,7 +257,7 @@ const char *fb_qnet_kernel_name(int kernel);
  * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
  * fb_qnet_apply_adam). */
 typedef struct {
-    uint8_t *nib;                                   /* u8[N,3200] */
+    uint8_t *nib;                                   /* u8[N,FB_NIB_STRIDE] */
     uint8_t *actions;                               /* u8[N] out */
     uint64_t *frame_bits;                           /* u64[N,100] out */
     float *reward; uint8_t *terminal; int32_t *score;   /* [N] out */

@@ -164,7 +164,12 @@ def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cu
     rep.reset(env.frame_bits)
 
     def unpack(nibt):
-        b = nibt.cpu().numpy()                                     # [N][3200]
+        from dqnflappybird_amd import _lib as L                     # [N][FB_NIB_STRIDE]: 84 padded rows of 4 + 40 bytes
+        raw = nibt.cpu().numpy()
+        full = raw[:, :L.NIB_ROWS * L.NIB_PITCH].reshape(N, L.NIB_ROWS, L.NIB_PITCH)
+        assert not full[:, :2].any() and not full[:, 82:].any() and not full[:, :, :4].any()      # conv1's zero padding
+        assert not raw[:, L.NIB_ROWS * L.NIB_PITCH:].any()
+        b = np.ascontiguousarray(full[:, 2:82, 4:])
         px = np.stack([b & 0x0F, b >> 4], axis=-1).reshape(N, 6400)   # nibble per pixel
         return (((px[..., None] >> np.arange(4)) & 1) * 255).astype(np.uint8).reshape(N, 80, 80, 4)
 
