@@ -1147,12 +1147,19 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
         int am[16];
         bool mok[16], in[16];
         int par[16];
+        // position c0 of the chunk is wave-uniform: its (sample, oy, ox) come from scalar divisions once; the 32 positions
+        // of the chunk then only carry an offset d < 32 through two small mul-shift quotients (exact for the ranges that
+        // can occur: OW = 20 or 5, d + ox0 < 64, oy0 + q < 32) instead of two 32-bit divisions per position and lane
+        const int c0s = __builtin_amdgcn_readfirstlane(c0);
+        const int b0 = c0s / OPIX, rem0 = c0s - b0 * OPIX, oy0 = rem0 / G::OW, ox0 = rem0 - oy0 * G::OW;
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            const int m0 = c0 + 2 * t + hl;
+            const int m0 = c0s + 2 * t + hl;
             mok[t] = m0 < mend;
-            const int m = mok[t] ? m0 : mbeg;
-            const int b = m / OPIX, rem = m - b * OPIX, oy = rem / G::OW, ox = rem - oy * G::OW;
+            const int d = mok[t] ? 2 * t + hl : 0;                  // rows past the end recompute position c0 (valid) and are masked
+            const int m = c0s + d;
+            const int xs = ox0 + d, q = G::OW == 20 ? (xs * 13) >> 8 : (xs * 205) >> 10, ox = xs - q * G::OW;
+            const int ys = oy0 + q, qq = G::OH == 20 ? (ys * 13) >> 8 : (ys * 205) >> 10, oy = ys - qq * G::OH, b = b0 + qq;
             const int iy = oy * G::S + ky - G::P;
             if (LAYER == 1) {
                 const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
