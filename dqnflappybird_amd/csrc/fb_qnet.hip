@@ -53,18 +53,34 @@ __device__ __forceinline__ void for_rows(int base, int limit, int lane, F body) 
     }
 }
 
-template <int NW>
-__device__ __forceinline__ void reduce_waves(f32x16 &acc, float *red, int wave, int lane) {
-    if (wave > 0 && wave < NW) {
+// Sum the accumulators of the first NW waves of a workgroup (>= 8 waves) and run the epilogue, with the work dealt out:
+// every contributing wave parks its 16 rows in LDS (red: NW * 16 * 64 floats), then wave k < 8 adds the NW partials
+// of rows 2k and 2k + 1 -- in wave order w = 0, 1, .., the same chain of fp32 adds a single reducing wave would run, so
+// the result is bit-identical -- and calls body(sum, r, base + drow(r)) for them.  Rows at or past `limit` are skipped
+// (whole tiles take the unguarded path, see for_rows).  One wave used to do all 16 x (NW - 1) adds and all 16 stores while
+// the others idled.
+template <int NW, class F>
+__device__ __forceinline__ void reduce_rows(const f32x16 &acc, float *red, int wave, int lane, int base, int limit, F body) {
+    if (wave < NW) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
     }
     __syncthreads();
-    if (wave == 0) {
-        for (int w = 1; w < NW; w++) {
+    if (wave >= 8) return;
+    float v[2];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] += red[((w - 1) * 16 + r) * 64 + lane];
-        }
+    for (int q = 0; q < 2; q++) {
+        const int r = 2 * wave + q;
+        v[q] = red[r * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; w++) v[q] += red[(w * 16 + r) * 64 + lane];
+    }
+    if (base + 32 <= limit) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) body(v[q], 2 * wave + q, base + drow(2 * wave + q, lane));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const int row = base + drow(2 * wave + q, lane); if (row < limit) body(v[q], 2 * wave + q, row); }
     }
 }
 
@@ -118,7 +134,7 @@ __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool
 // ================================================================== forward
 // conv2 4x4x32->64 stride 2 SAME(1,1) + bias + relu; 8 waves = 16 kernel cells / 2
 __global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[8 * 16 * 64];
     const Slice s = sl.s[blockIdx.z];
     const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
     if (tile * 32 >= M) return;
@@ -131,16 +147,13 @@ __global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__re
     const float *bcol = s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j;
     f32x16 acc = {0};
     mma_run_col<32>(arun, ok, bcol, 64, acc);
-    reduce_waves<8>(acc, red, wave, lane);
-    if (wave == 0) {
-        const float bias = s.params[OFF_B2 + n0 + j];
-        for_rows(tile * 32, M, lane, [&](int r, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
-    }
+    const float bias = s.params[OFF_B2 + n0 + j];
+    reduce_rows<8>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
 }
 
 // conv3 3x3x64->64 stride 1 SAME(1,1) + bias + relu; 9 waves = 9 kernel cells
 __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
-    __shared__ float red[8 * 16 * 64];
+    __shared__ float red[9 * 16 * 64];
     const Slice s = sl.s[blockIdx.z];
     const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
     if (tile * 32 >= M) return;
@@ -153,11 +166,8 @@ __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__re
     const float *bcol = s.params + OFF_W3 + ((size_t)(wave * 64) + 32 * hl) * 64 + n0 + j;
     f32x16 acc = {0};
     mma_run_col<32>(arun, ok, bcol, 64, acc);
-    reduce_waves<9>(acc, red, wave, lane);
-    if (wave == 0) {
-        const float bias = s.params[OFF_B3 + n0 + j];
-        for_rows(tile * 32, M, lane, [&](int r, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
-    }
+    const float bias = s.params[OFF_B3 + n0 + j];
+    reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
 }
 
 // ---- conv1 on the bf16 matrix cores, exactly.
@@ -386,7 +396,7 @@ constexpr int FC1_KS = 5;
 
 __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
                                                   int stot) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[8 * 16 * 64];
     const int z = blockIdx.z / FC1_KS, ks = blockIdx.z - z * FC1_KS;
     const Slice s = sl.s[z];
     const int M = s.count, tile = blockIdx.x, n0 = blockIdx.y * 32;
@@ -399,10 +409,7 @@ __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__rest
     const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
     f32x16 acc = {0};
     mma_run_col<20>(arun, ok, bcol, FC, acc);
-    reduce_waves<8>(acc, red, wave, lane);
-    if (wave == 0) {
-        for_rows(tile * 32, M, lane, [&](int r, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r]; });
-    }
+    reduce_rows<8>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = v; });
 }
 
 // large-batch fc1: one wave = one m-tile x one n-tile x one of FC1_BIG_KS = 2 k-slices (800 k = 20 steps of 20 k
@@ -1102,13 +1109,10 @@ __device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__
     int c = 0;
     for (; c + 32 <= kh; c += 32) mma_run_run<32>(arun + c, ok, brun + c, acc);
     for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc);
-    reduce_waves<8>(acc, red, wave, lane);
-    if (wave == 0) {
-        for_rows(mt * 32, B, lane, [&](int r, int mr) {
-            const size_t o = (size_t)mr * 1600 + kt * 32 + j;
-            dh3[o] = h3[o] > 0.f ? acc[r] : 0.f;
-        });
-    }
+    reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
+        const size_t o = (size_t)mr * 1600 + kt * 32 + j;
+        dh3[o] = h3[o] > 0.f ? v : 0.f;
+    });
 }
 
 // conv weight (+ bias) gradients: dW[(cell, ci)][co] = sum_m X[m @ cell][ci] * dY[m][co], db[co] = sum_m dY[m][co].
@@ -1187,19 +1191,15 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = mfma(a[t], bb[t], acc);
     }
-    reduce_waves<8>(acc, red, wave, lane);
-    if (wave == 0) {
-        float *o = slabs + zslab * slab_stride;
+    float *o = slabs + zslab * slab_stride;
+    reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
         if (bias_tile) {
-            if (hl == 0) o[G::BOFF + cot * 32 + j] = acc[0];                         // row 0 = column sums
+            if (row32 == 0) o[G::BOFF + cot * 32 + j] = v;                           // row 0 = column sums
         } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = LAYER == 1 ? (ky * 32 + drow(r, lane)) : (cell * G::CI + cit * 32 + drow(r, lane));
-                o[G::WOFF + (size_t)row * G::CO + cot * 32 + j] = acc[r];
-            }
+            const int row = LAYER == 1 ? (ky * 32 + row32) : (cell * G::CI + cit * 32 + row32);
+            o[G::WOFF + (size_t)row * G::CO + cot * 32 + j] = v;
         }
-    }
+    });
 }
 
 // conv3 data gradient -> dh2 (masked by relu2); 9 waves = 9 cells
@@ -1215,10 +1215,7 @@ __device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *
     const float *brun = params + OFF_W3 + ((size_t)(wave * 64) + c0 + j) * 64 + 32 * hl;
     f32x16 acc = {0};
     mma_run_run<32>(arun, ok, brun, acc);
-    reduce_waves<9>(acc, red, wave, lane);
-    if (wave == 0) {
-        for_rows(tile * 32, M, lane, [&](int r, int mr) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? acc[r] : 0.f; });
-    }
+    reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? v : 0.f; });
 }
 
 // conv2 data gradient -> dp1 (masked by relu1 through the pool: p1 > 0).  Stride 2 means an input pixel
@@ -1239,14 +1236,11 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
     const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
     f32x16 acc = {0};
     if (wave < 4) mma_run_run<32>(arun, ok, brun, acc);
-    reduce_waves<4>(acc, red, wave, lane);
-    if (wave == 0) {
-        for_rows(tile * 32, M, lane, [&](int r, int mr) {
-            const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
-            const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
-            dp1[o] = p1[o] > 0.f ? acc[r] : 0.f;
-        });
-    }
+    reduce_rows<4>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) {
+        const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
+        const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
+        dp1[o] = p1[o] > 0.f ? v : 0.f;
+    });
 }
 
 // ---- merged backward launches: the weight-gradient tiles and the data-gradient tiles of one layer are
@@ -1255,7 +1249,7 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
 __global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
                                                       const float *__restrict__ dhf, float *__restrict__ dh3,
                                                       float *__restrict__ grad, int B, int FC) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[8 * 16 * 64];
     if ((int)blockIdx.x < n_dx) fc1_dx_body(blockIdx.x, red, params, h3, dhf, dh3, B, FC);
     else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC);
 }
@@ -1263,7 +1257,7 @@ __global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__r
 __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh3, const float *__restrict__ h2,
                                                         float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B) {
-    __shared__ float red[8 * 16 * 64];
+    __shared__ float red[9 * 16 * 64];
     if ((int)blockIdx.x < n_dx) conv3_dx_body(blockIdx.x, red, params, dh3, h2, dh2, B);
     else {
         const int t = blockIdx.x - n_dx;
@@ -1274,7 +1268,7 @@ __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const 
 __global__ __launch_bounds__(512) void conv2_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh2, const float *__restrict__ p1,
                                                         float *__restrict__ dp1, float *__restrict__ slabs, size_t slab_stride, int B) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[8 * 16 * 64];
     if ((int)blockIdx.x < n_dx) conv2_dx_body(blockIdx.x, red, params, dh2, p1, dp1, B);
     else {
         const int t = blockIdx.x - n_dx;
@@ -1285,7 +1279,7 @@ __global__ __launch_bounds__(512) void conv2_bwd_kernel(int n_dx, int nz, const 
 __global__ __launch_bounds__(512) void conv1_dw_kernel(int nz, const uint8_t *__restrict__ states, const float *__restrict__ dp1,
                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs,
                                                        size_t slab_stride, int B) {
-    __shared__ float red[7 * 16 * 64];
+    __shared__ float red[8 * 16 * 64];
     conv_dw_body<1>(blockIdx.x % 9, blockIdx.x / 9, nz, red, B, nullptr, states, dp1, amax, slabs, slab_stride);
 }
 
