@@ -30,7 +30,6 @@ constexpr size_t BLOB_BYTES = 8 + 4 + 1024 + PIPE_H * PIPE_W + 3 * BIRD_H * BIRD
 
 struct alignas(16) EnvLds {      // staged into LDS by every workgroup
     uint32_t pal[256];
-    uint8_t pipe[PIPE_H * PIPE_W];
     uint8_t bird[3 * BIRD_H * BIRD_W];
     uint32_t ground_bits[12 * OBS];      // [basex / -4][r] bit (c - 63)
     int16_t xo[OBS], xb0[OBS], xb1[OBS]; // game-x taps per output row r (cv vertical pass)
@@ -48,6 +47,9 @@ static_assert(sizeof(EnvLds) % 16 == 0, "EnvLds must be a multiple of 16 bytes")
 
 struct EnvConst {
     EnvLds l;
+    // the raw pipe sprite stays in global memory (L2): with the pre-rendered row masks only the pixel-exact collision
+    // test and the rows where bird and pipe meet still read it, and those touch a few hundred bytes of it per step
+    uint8_t pipe[PIPE_H * PIPE_W];
     uint8_t base[BASE_H * BASE_W];       // only fb_env_render_full needs the raw ground sprite
 };
 
@@ -86,7 +88,7 @@ __device__ __forceinline__ void env_reset(const EnvParams &p, int env, int32_t *
 }
 
 // palette index of the topmost pipe pixel at canvas (x, y), 0 if none; y < BASEY_I
-__device__ __forceinline__ int pipe_at(const EnvLds &L, const int32_t *st, int x, int y) {
+__device__ __forceinline__ int pipe_at(const uint8_t *__restrict__ pipe, const int32_t *st, int x, int y) {
     int idx = 0;
     const int n = st[6];
 #pragma unroll
@@ -94,8 +96,8 @@ __device__ __forceinline__ int pipe_at(const EnvLds &L, const int32_t *st, int x
         int col = x - st[7 + i];
         if (i < n && col >= 0 && col < PIPE_W) {
             int gy = gap_y(st[10 + i]);
-            if (y < gy) idx = L.pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];   // upper = rotated by 180
-            else if (y >= gy + GAP) idx = L.pipe[(y - gy - GAP) * PIPE_W + col];
+            if (y < gy) idx = pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];     // upper = rotated by 180
+            else if (y >= gy + GAP) idx = pipe[(y - gy - GAP) * PIPE_W + col];
         }
     }
     return idx;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                         const int bx = i % BIRD_W, by = i / BIRD_W;
                         if (L.bird[(st[2] * BIRD_H + by) * BIRD_W + bx]) {
                             const int y = st[0] + by;
-                            if (y < BASEY_I && pipe_at(L, st, PLAYERX + bx, y)) hit = 1;
+                            if (y < BASEY_I && pipe_at(p.cst->pipe, st, PLAYERX + bx, y)) hit = 1;
                         }
                     }
                 }
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                     int v = 0;
                     if (bcol[tx] >= 0 && by >= 0 && by < BIRD_H) v = L.bird[(pidx * BIRD_H + by) * BIRD_W + bcol[tx]];
                     if (!v && pcol[tx] >= 0) {
-                        if (y < pgy[tx]) v = L.pipe[(pgy[tx] - 1 - y) * PIPE_W + (PIPE_W - 1 - pcol[tx])];
-                        else if (y >= pgy[tx] + GAP) v = L.pipe[(y - pgy[tx] - GAP) * PIPE_W + pcol[tx]];
+                        if (y < pgy[tx]) v = p.cst->pipe[(pgy[tx] - 1 - y) * PIPE_W + (PIPE_W - 1 - pcol[tx])];
+                        else if (y >= pgy[tx] + GAP) v = p.cst->pipe[(y - pgy[tx] - GAP) * PIPE_W + pcol[tx]];
                     }
                     idx[tx][ty] = v;
                 }
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void render_full_kernel(EnvParams p, int env, 
         int idx = bird_at(C.l, st, x, y);
         if (!idx) {
             if (y >= BASEY_I) { const int by = y - BASEY_I; idx = by < BASE_H ? C.base[by * BASE_W + (x - st[4])] : 0; }
-            else idx = pipe_at(C.l, st, x, y);
+            else idx = pipe_at(C.pipe, st, x, y);
         }
         const uint32_t c = C.l.pal[idx];
         rgb[(size_t)i * 3 + 0] = c & 255; rgb[(size_t)i * 3 + 1] = (c >> 8) & 255; rgb[(size_t)i * 3 + 2] = (c >> 16) & 255;
@@ -456,7 +458,7 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
     EnvConst *hc = new EnvConst();
     const uint8_t *b = (const uint8_t *)blob + 12;
     memcpy(hc->l.pal, b, 1024); b += 1024;
-    memcpy(hc->l.pipe, b, sizeof(hc->l.pipe)); b += sizeof(hc->l.pipe);
+    memcpy(hc->pipe, b, sizeof(hc->pipe)); b += sizeof(hc->pipe);
     memcpy(hc->l.bird, b, sizeof(hc->l.bird)); b += sizeof(hc->l.bird);
     memcpy(hc->base, b, sizeof(hc->base));
     linear_tab(OBS, SH, hc->l.yo, hc->l.ya0, hc->l.ya1);      // cv columns = game y (512)
@@ -491,8 +493,8 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
     auto pipe_px = [&](int g, int col, int y) -> int {         // wrapped_flappy_bird.py:165-170, upper pipe rotated by 180
         if (col < 0 || col >= PIPE_W) return 0;
         const int gy = 100 + 10 * g;
-        if (y < gy) return hc->l.pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];
-        if (y >= gy + GAP) return hc->l.pipe[(y - gy - GAP) * PIPE_W + col];
+        if (y < gy) return hc->pipe[(gy - 1 - y) * PIPE_W + (PIPE_W - 1 - col)];
+        if (y >= gy + GAP) return hc->pipe[(y - gy - GAP) * PIPE_W + col];
         return 0;
     };
     for (int g = 0; g < 8; g++)

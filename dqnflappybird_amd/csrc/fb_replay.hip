@@ -205,6 +205,29 @@ __device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k
     if (n > setsize) {
         const int shift = __builtin_clz((uint32_t)n);   // 32 - n.bit_length()
         int i = 0;
+        if (k <= 64) {
+            // Optimistic path: if the next <= 64 words hold k candidates below n and those are pairwise distinct (all but
+            // ~k^2 / 2n of the calls), they ARE the sample, in stream order -- decided with a ballot, a rank and one round
+            // of wave shuffles instead of k dependent iterations.  Otherwise nothing has been consumed and the loop runs.
+            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
+            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
+            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
+            const bool valid = lane < take && w < (uint32_t)n;
+            const unsigned long long mask = __ballot(valid);
+            if (__popcll(mask) >= k) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                if (valid && rank < k) pool[rank] = (int)w;
+                __syncthreads();                        // one wave per workgroup: orders the LDS writes before the reads
+                const uint32_t c = lane < k ? (uint32_t)pool[lane] : (0x80000000u | (uint32_t)lane);   // distinct sentinels past k
+                bool dup = false;
+                for (int d = 1; d < 64; d++) dup |= (uint32_t)__shfl((int)c, (lane + d) & 63) == c;
+                if (!__any(dup)) {
+                    if (lane < k) sel[0] = (long long)c;
+                    idx += __builtin_ctzll(__ballot(valid && rank == k - 1)) + 1;     // up to and including the k-th candidate
+                    i = k;
+                }
+            }
+        }
         while (i < k) {
             if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
             const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
