@@ -137,8 +137,10 @@ int fb_replay_reset(fb_replay_t h, const uint8_t *frames /*[dev] u8[N,80,80] or 
                     const uint64_t *frame_bits /*[dev] u64[N,100] or NULL*/, void *stream);
 /* setPerception's store: one transition per env (env order = deque order within a step).
  * Exactly one of frames / frame_bits is given (the NEXT observation).  The handle counts pushes on
- * the host (the kernel receives the step index by value), so unlike sample / gather / train a push
- * must not be replayed from a captured hipGraph. */
+ * the host (the kernels receive the step index by value), so a push must not be replayed from a captured
+ * hipGraph, and a captured fb_replay_gather / fb_replay_current_state addresses the memory as it was filled at
+ * capture time (fine for replaying train steps on a memory that is not being pushed to; sample / train have no
+ * such restriction). */
 int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64_t *frame_bits, const uint8_t *actions,
                    const float *rewards, const uint8_t *terminals, void *stream);
 /* fb_replay_push followed by fb_replay_sample(batch) of a uniform memory, in one launch: identical results
