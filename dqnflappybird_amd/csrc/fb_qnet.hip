@@ -474,16 +474,10 @@ __global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restric
 
 // conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
 // L1/L2 traffic at 1024 states); here a workgroup parks them in LDS once and its waves walk over tiles, the
-// next tile's input bytes in flight while the current one is in the MFMAs.  Operands are swapped (D = W^T x A^T):
-// a lane then holds 16 channels of ONE window position, the 2x2 pool is a max over the 4 lanes of a quad (DPP),
-// and every lane stores 4 consecutive channels of a pooled pixel as 8 bytes per plane (512 B per wave, contiguous).
-__device__ __forceinline__ float quad_max(float v) {
-    int x = __float_as_int(v);
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));      // quad_perm [1,0,3,2]
-    x = __float_as_int(v);
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
-}
-
+// next tile's input bytes in flight while the current one is in the MFMAs.  The vector ALU is the scarce unit here
+// (48 MFMAs per tile leave room for ~250 vector instructions): taps are immediate offsets into the SAME-padded nibble
+// image, the 2x2 pool is a max over four registers of a lane, and a quad transpose hands every lane 4 consecutive
+// channels of one pooled pixel for an 8-byte store per plane (512 B per wave, contiguous).
 #ifndef FB_C1_WAVES
 #define FB_C1_WAVES 3
 #endif
