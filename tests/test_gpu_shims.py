@@ -151,13 +151,13 @@ def test_checkpoint_resume_on_device(torch_cuda, oracle, tmp_path):
     assert torch_cuda.equal(a.net.forward(st), b.net.forward(st))
 
 
-def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cuda):
+@pytest.mark.parametrize("N", [7, 64, 300])      # < 256: the fp32-MFMA kernels; >= 256: the split-bf16 acting kernels
+def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cuda, N):
     """The env kernel's running 4-frame nibble state == the replay ring's currentState (BrainDQN.py:68,238-239),
     and the acting forward that consumes it gives bit-identical Q / actions to the u8 path."""
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
-    N = 300                                   # >= 256: the large-batch kernels
-    env, rep, net = VecGameState(N, seed=3), VecReplay(5000, N), QNet(max_batch=N)
+    env, rep, net = VecGameState(N, seed=3), VecReplay(5000, N), QNet(max_batch=max(N, 8))
     net.init_params(seed=1)
     nib = env.track_state()
     env.observe()
