@@ -1160,19 +1160,20 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
             const int ys = oy0 + q, qq = G::OH == 20 ? (ys * 13) >> 8 : (ys * 205) >> 10, oy = ys - qq * G::OH, b = b0 + qq;
             const int iy = oy * G::S + ky - G::P;
             if (LAYER == 1) {
-                const size_t po = ((size_t)b * 100 + (oy >> 1) * 10 + (ox >> 1)) * 32 + j;
+                // 32-bit unsigned indices (B <= 256: all far below 2^32): no sign extension, no 64-bit multiplies
+                const uint32_t po = ((uint32_t)b * 100u + (uint32_t)((oy >> 1) * 10 + (ox >> 1))) * 32u + (uint32_t)j;
                 am[t] = amax[po];
                 dv[t] = dy[po];
                 par[t] = (oy & 1) * 2 + (ox & 1);
                 const int ix = ox * 4 - 2 + (i >> 2);
                 in[t] = iy >= 0 && iy < 80 && ix >= 0 && ix < 80;
-                xv[t] = (float)xu8[(((size_t)b * 80 + (in[t] ? iy : 0)) * 80 + (in[t] ? ix : 0)) * 4 + (i & 3)];
+                xv[t] = (float)xu8[(((uint32_t)b * 80u + (uint32_t)(in[t] ? iy : 0)) * 80u + (uint32_t)(in[t] ? ix : 0)) * 4u + (uint32_t)(i & 3)];
             } else {
                 am[t] = 0; par[t] = 0;
-                dv[t] = dy[(size_t)m * G::CO + cot * 32 + j];
+                dv[t] = dy[(uint32_t)m * (uint32_t)G::CO + (uint32_t)(cot * 32 + j)];
                 const int ix = ox * G::S + kx - G::P;
                 in[t] = iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
-                xv[t] = x[(((size_t)b * G::IH + (in[t] ? iy : 0)) * G::IW + (in[t] ? ix : 0)) * G::CI + cit * 32 + i];
+                xv[t] = x[(((uint32_t)b * G::IH + (uint32_t)(in[t] ? iy : 0)) * G::IW + (uint32_t)(in[t] ? ix : 0)) * G::CI + (uint32_t)(cit * 32 + i)];
             }
         }
 #pragma unroll
