@@ -1366,6 +1366,7 @@ struct fb_qnet {
     uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
     uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [3][S*3200], conv3 out [3][S*1600] bf16
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
+    bool adam_ticked;                // a data-parallel train step already advanced beta1^t / beta2^t for the apply_adam that follows
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
@@ -1602,7 +1603,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
             L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = big ? FC1_BIG_KS : FC1_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
             L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
-            L.adam = h->adam; L.tick = p.tick;
+            // data-parallel path: the loss kernel advances the Adam step counter as well (once per fb_qnet_apply_adam), so the
+            // apply needs no launch of its own for it
+            const bool tick = p.tick && !h->adam_ticked;            // at most one tick per Adam update
+            if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
+            L.adam = h->adam; L.tick = tick;
             hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
         }
         // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
@@ -1676,7 +1681,8 @@ extern "C" int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, fl
 extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream) {
     FB_REQUIRE(h && flat_grad, "fb_qnet_apply_adam: NULL argument");
     hipStream_t st = fb_stream(stream);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
+    if (!h->adam_ticked) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);     // gradients that did not come from fb_qnet_train_step
+    h->adam_ticked = false;
     hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
                        (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0]);
     h->wsp_stale[0] = true;
@@ -1709,7 +1715,7 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
     p.train = true; p.algo = algo; p.B = B; p.s = s; p.a = a; p.r = r; p.t = t; p.isw = isw; p.gamma = gamma;
     p.loss = loss; p.abs_err = abs_err; p.y = q_target;
     p.G = flat_grad ? flat_grad : h->grad;
-    p.apply_adam = flat_grad == nullptr; p.tick = flat_grad == nullptr;
+    p.apply_adam = flat_grad == nullptr; p.tick = true;
     *out = p;
     return FB_OK;
 }
