@@ -1278,6 +1278,23 @@ __global__ __launch_bounds__(512) void conv1_dw_kernel(int nz, const uint8_t *__
     conv_dw_body<1>(blockIdx.x % 9, blockIdx.x / 9, nz, red, B, nullptr, states, dp1, amax, slabs, slab_stride);
 }
 
+// Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
+// walk up to 7 chunks one after the other (94 us at B = 256).  It is cut into up to 4 x 64 sub-slabs instead (one chunk
+// per wave again) and this kernel folds groups of 4 into the 64 slabs the Adam kernel sums, in a fixed order.
+constexpr int FOLD = 4, CONV1_PARAMS = OFF_W2;       // W_conv1 + b_conv1 open a slab
+__global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, float *__restrict__ slabs, size_t slab_stride) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (idx >= CONV1_PARAMS) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < FOLD; q++) {
+        const int z = s * FOLD + q;
+        const float x = sub[(size_t)(z < nsub ? z : 0) * CONV1_PARAMS + idx];
+        v += z < nsub ? x : 0.f;
+    }
+    slabs[s * slab_stride + idx] = v;
+}
+
 // sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
                                    float *__restrict__ grad) {
@@ -1360,6 +1377,7 @@ struct fb_qnet {
     long long n;
     NetOff off;
     float *params[2], *adam_m, *adam_v, *grad, *slabs;
+    float *slabs1;                   // conv1 sub-slabs of large batches (slab_fold_kernel), NULL when max_batch never needs them
     uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
     uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
     bool wsp_stale[2];               // parameters changed since wsp was built
@@ -1402,6 +1420,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->params[0], nb); alloc((void **)&h->params[1], nb);
     alloc((void **)&h->adam_m, nb); alloc((void **)&h->adam_v, nb); alloc((void **)&h->grad, nb);
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
+    if ((max_batch * 400 + 255) / 256 > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)FOLD * h->zmax * CONV1_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
     const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)(200 + 4) * 3 * fc_width) * sizeof(uint4);   // + one chunk: fc1_sp_kernel over-reads
@@ -1426,7 +1445,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
-    void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->adam, h->p1, h->amax, h->h2,
+    void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->slabs1, h->adam, h->p1, h->amax, h->h2,
                     h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -1624,7 +1643,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         const int ndx2 = ((B * 25 + 31) / 32) * 4;
         FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
                                              h->dp1, h->slabs, ss, B);
-        FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * z1), dim3(512), 0, st, z1, p.s, h->dp1, h->amax, h->slabs, ss, B);
+        int zsub = (B * 400 + 255) / 256;                      // one 32-pixel chunk per wave when there is room for it
+        if (zsub > FOLD * h->zmax) zsub = FOLD * h->zmax;
+        if (zsub > h->zmax) {
+            z1 = (zsub + FOLD - 1) / FOLD;
+            FB_K(K_CONV1_DW) {
+                hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * zsub), dim3(512), 0, st, zsub, p.s, h->dp1, h->amax, h->slabs1, (size_t)CONV1_PARAMS, B);
+                hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, zsub, h->slabs, ss);
+            }
+        } else FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * z1), dim3(512), 0, st, z1, p.s, h->dp1, h->amax, h->slabs, ss, B);
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
