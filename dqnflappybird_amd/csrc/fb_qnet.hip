@@ -610,6 +610,15 @@ struct C23Args {
     int n;
 };
 
+#ifndef C23_NO_LDSR
+#define C23_NO_LDSR 0
+#endif
+#ifndef C23_NO_W
+#define C23_NO_W 0
+#endif
+#ifndef C23_NO_BAR
+#define C23_NO_BAR 0
+#endif
 template <int NS>
 __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NS * IN_P, RING = ZOFF + 16, RSZ = 4 * NS * 64;   // uint4 units
@@ -680,11 +689,18 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     };
     f32x16 acc[2] = {{0}, {0}};
     auto compute = [&](const Fr f) {
+        // NB the MFMA intrinsics are pure: nothing but a data dependence orders them.  Without the ordered use of the
+        // accumulators at the head of each FB_STEP hipcc hoists them across the barrier to right behind the LDS reads that
+        // produce their operands (reads -> wait -> MFMA: no prefetch distance at all)
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
+#ifdef C23_NO_MFMA
+#define FB_M(pa, pb) acc[ct][0] += __builtin_bit_cast(float, f.W[s][ct][pb].x ^ f.A[s][pa].x)
+#else
 #define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.W[s][ct][pb]), __builtin_bit_cast(bf16x8, f.A[s][pa]), acc[ct], 0, 0, 0)
+#endif
                 if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }      // small terms first
                 FB_M(0, 0);
 #undef FB_M
@@ -710,13 +726,18 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     __syncthreads();
 #define FB_STEP(cc, ST, AIDX_NEXT, HAVE_A)                                                                        \
     {                                                                                                                  \
-        Fr nx = cur;                                                                                                   \
-        if ((cc) + 1 < 34) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }                        \
-        __builtin_amdgcn_sched_barrier(0);      /* keep the prefetch reads ahead of the MFMAs (hipcc sinks them to their uses) */ \
-        compute(cur);                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if ((cc) + 2 < 34) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); }                    \
-        __syncthreads();                                                                                               \
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));     /* see compute(): chunk cc's MFMAs stay behind chunk cc - 1's barrier */ \
+        Fr nx = cur;                                                                                                   \
+        if ((cc) + 1 < 34 && !C23_NO_LDSR) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }        \
+        compute(cur);                                                                                                  \
+        if ((cc) + 2 < 34 && !C23_NO_W) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); }       \
+        /* issue order inside the chunk: one LDS read / ring write / global load behind each MFMA, so that the LDS pipe   \
+           and the MFMA pipe run side by side instead of in two phases that the per-chunk barrier keeps in lock step */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 18; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+        if (!C23_NO_BAR) __syncthreads();                                                                              \
         cur = nx;                                                                                                      \
     }
     // relu(acc + bias) of this lane's 32 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half)
@@ -830,6 +851,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     };
     f32x16 acc[2] = {{0}, {0}};
     auto compute = [&](const Fr f) {
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));       // ordered use: pins the (pure) MFMAs between the sched_barriers (see conv23)
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
 #define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[pa]), __builtin_bit_cast(bf16x8, f.W[ct][pb]), acc[ct], 0, 0, 0)
@@ -837,6 +859,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
             FB_M(0, 0);
 #undef FB_M
         }
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));
     };
     St stA = load(0), stB = load(1);
     store(0, stA); stA = load(2);
