@@ -478,12 +478,14 @@ __global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restric
 // (48 MFMAs per tile leave room for ~250 vector instructions): taps are immediate offsets into the SAME-padded nibble
 // image, the 2x2 pool is a max over four registers of a lane, and a quad transpose hands every lane 4 consecutive
 // channels of one pooled pixel for an 8-byte store per plane (512 B per wave, contiguous).
+// One workgroup of 12 waves per CU (3 per SIMD, <= 168 VGPRs): one copy of the weights per CU, and 12800 tiles over
+// 3072 waves leave every SIMD 12 or 13 tiles (640 workgroups of 4 waves left some CUs with 3 workgroups = 15 tiles
+// per SIMD and others with 2).  When the step changed the parameters every thread first re-splits at most one
+// 8-weight item of W_conv2 / W_conv3 / W_fc1 for the kernels that follow (wsplit_item) -- no launch of its own.
 #ifndef FB_C1_WAVES
-#define FB_C1_WAVES 3
+#define FB_C1_WAVES 12
 #endif
-// The first `nws` workgroups of the launch do not convolve: they re-split W_conv2 / W_conv3 / W_fc1 for the kernels
-// that follow (wsplit_item; only when the step changed the parameters) -- one launch and its cold start less.
-constexpr int WS_BLOCKS = 64;
+constexpr int C1_WAVES = FB_C1_WAVES;
 // 4 x 4 transpose inside every quad of lanes: lane l ends with v[c] = (lane c's v[l]).  Two butterfly stages (partners
 // l ^ 1, then l ^ 2), 16 vector instructions.
 __device__ __forceinline__ float dpp_x1(float v) { const int x = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)); }
@@ -497,18 +499,17 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int l) {
 }
 
 template <bool NIB>
-__global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
-                                                                     size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int nws) {
+__global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
+                                                                  size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int resplit) {
     __shared__ uint4 wl[3 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
-    if ((int)blockIdx.x < nws) {
+    if (resplit) {
         const int items = 64 * 64 + 72 * 64 + 200 * FC;
-        for (int id = blockIdx.x * 256 + threadIdx.x; id < items; id += nws * 256) wsplit_item(s.params, wsp, FC, id);
-        return;
+        for (int id = blockIdx.x * (64 * C1_WAVES) + threadIdx.x; id < items; id += gridDim.x * (64 * C1_WAVES)) wsplit_item(s.params, wsp, FC, id);
     }
-    const int bid = blockIdx.x - nws, nblk = gridDim.x - nws;
-    for (int q = threadIdx.x; q < 3 * 16 * 64; q += 256) wl[q] = reinterpret_cast<const uint4 *>(s.w1s)[q];
-    if (NIB) {
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    for (int q = threadIdx.x; q < 3 * 16 * 64; q += 64 * C1_WAVES) wl[q] = reinterpret_cast<const uint4 *>(s.w1s)[q];
+    if (NIB && threadIdx.x < 256) {
         const unsigned t = threadIdx.x;
         uint4 e;
         e.x = ((t >> 0) & 1u) * 0x437Fu | ((t >> 1) & 1u) * 0x437F0000u;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
     __syncthreads();
     typedef typename std::conditional<NIB, unsigned, uint2>::type Raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31, pp = j >> 2, pos = j & 3;
-    const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = nblk * 4;
+    const int npool = s.count * 100, ntiles = (npool + 7) / 8, stride = nblk * C1_WAVES;
     const float bias = s.params[OFF_B1 + j];
     auto fetch = [&](int tile, Raw (&raw)[16]) {
         const int P0 = tile * 8 + pp, P = P0 < npool ? P0 : 0;       // rows past the end compute on state 0 and are not stored
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256, FB_C1_WAVES) void conv1_sp_kernel(Slice s, con
             }
         }
     };
-    int tile = bid * 4 + wave;
+    int tile = bid * C1_WAVES + wave;
     if (tile >= ntiles) return;
     Raw cur[16], nxt[16];
     fetch(tile, cur);
@@ -851,7 +852,6 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     };
     f32x16 acc[2] = {{0}, {0}};
     auto compute = [&](const Fr f) {
-        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));       // ordered use: pins the (pure) MFMAs between the sched_barriers (see conv23)
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
 #define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[pa]), __builtin_bit_cast(bf16x8, f.W[ct][pb]), acc[ct], 0, 0, 0)
@@ -859,7 +859,6 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
             FB_M(0, 0);
 #undef FB_M
         }
-        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));
     };
     St stA = load(0), stB = load(1);
     store(0, stA); stA = load(2);
@@ -1587,7 +1586,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     // only a later kernel of the plan is requested)
     int nws = 0;
     if (sp && h->wsp_stale[p.which]) {
-        if (only < 0 || only == K_CONV1) nws = WS_BLOCKS;
+        if (only < 0 || only == K_CONV1) nws = 1;
         else {
             const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
             hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, p.sl.s[0].params, h->wsp[p.which], h->FC);
@@ -1597,10 +1596,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
         if (sp) {
-            // persistent: every wave takes `rounds` tiles, about 3 workgroups per CU
-            const int rounds = (t1 + 3071) / 3072, gsp = (t1 + 4 * rounds - 1) / (4 * rounds);
-            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp + nws), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
-            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp + nws), dim3(256), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
+            // persistent: one 12-wave workgroup per CU, the waves stride over the tiles
+            const int gsp = min(256, (t1 + C1_WAVES - 1) / C1_WAVES);
+            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
+            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
         } else if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
         else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
