@@ -255,10 +255,12 @@ def main():
                                                                   L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
             if name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
+            elif name == "conv3_bwd_kernel":                  # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
+                add(name + "[+ Adam of W_fc1]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
             elif name in BWD_FLOP:
                 add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
             elif name == "adam_kernel":
-                add(name, us, 1, "hbm", ADAM_BYTES * net.n_params)
+                add(name + "[all but W_fc1]", us, 1, "hbm", ADAM_BYTES * (net.n_params - 1600 * 512))
             else:
                 add(name, us, 1, "hbm", 0)
         us = ev_time(lambda: L.check(lib.fb_replay_profile_gather(replay.h, BATCH, L.ptr(idx), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r),

@@ -1271,11 +1271,38 @@ __global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__r
     else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC);
 }
 
+// TF ApplyAdam on four consecutive parameters (the one definition both Adam paths use)
+__device__ __forceinline__ void adam4(float4 &P, float4 &Mv, float4 &V, const float4 Gv, float alpha, float omb1, float omb2, float eps) {
+#define FB_ADAM1(c)                                  \
+    Mv.c += (Gv.c - Mv.c) * omb1;                    \
+    V.c += (Gv.c * Gv.c - V.c) * omb2;               \
+    P.c -= (Mv.c * alpha) / (sqrtf(V.c) + eps);
+    FB_ADAM1(x) FB_ADAM1(y) FB_ADAM1(z) FB_ADAM1(w)
+#undef FB_ADAM1
+}
+
+// W_fc1 is 91 % of the parameters and its gradient is complete once fc1_bwd_kernel has run, while the three launches
+// that follow (conv3 / conv2 / conv1 backward) neither read W_fc1 nor fill more than ~200 of the 256 CUs, and wait on
+// latency rather than on HBM.  Its Adam update therefore rides as extra workgroups at the END of the conv3 backward
+// launch (float4 range [q0, q1) of the flat parameter vector); adam_kernel at the end of the step skips that range.
+struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; };
+__device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan a) {
+    const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
+    for (int q = a.q0 + blk * (int)blockDim.x + (int)threadIdx.x; q < a.q1; q += nblk * (int)blockDim.x) {
+        float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
+        adam4(P, Mv, V, reinterpret_cast<const float4 *>(a.g)[q], alpha, omb1, omb2, eps);
+        reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
+    }
+}
+
 __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh3, const float *__restrict__ h2,
-                                                        float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B) {
+                                                        float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B,
+                                                        int n_adam, AdamSpan span) {
     __shared__ float red[9 * 16 * 64];
-    if ((int)blockIdx.x < n_dx) conv3_dx_body(blockIdx.x, red, params, dh3, h2, dh2, B);
+    const int n_conv = gridDim.x - n_adam;
+    if ((int)blockIdx.x >= n_conv) adam_span_body(blockIdx.x - n_conv, n_adam, span);
+    else if ((int)blockIdx.x < n_dx) conv3_dx_body(blockIdx.x, red, params, dh3, h2, dh2, B);
     else {
         const int t = blockIdx.x - n_dx;
         conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride);
@@ -1334,10 +1361,11 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
                                                    const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad,
                                                    const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
-                                                   uint16_t *__restrict__ w1s) {
+                                                   uint16_t *__restrict__ w1s, int skip0, int skip1) {
     const float alpha = ad->alpha, omb1 = 1.f - ad->b1, omb2 = 1.f - ad->b2, eps = ad->eps;
-    const long long n4 = n >> 2;
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    const long long n4 = n >> 2, nq = n4 - (skip1 - skip0);      // float4s [skip0, skip1) were updated by an AdamSpan already
+    for (long long qq = (long long)blockIdx.x * 256 + threadIdx.x; qq < nq; qq += (long long)gridDim.x * 256) {
+        const long long q = qq < skip0 ? qq : qq + (skip1 - skip0);
         float4 P = reinterpret_cast<float4 *>(p)[q], Mv = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
         float4 Gv;
         if (slabs && q * 4 < CONV_PARAMS) {                      // region boundaries are multiples of 4
@@ -1349,12 +1377,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
                 Gv.x += t.x; Gv.y += t.y; Gv.z += t.z; Gv.w += t.w;
             }
         } else Gv = reinterpret_cast<const float4 *>(g)[q];
-#define FB_ADAM1(c)                                  \
-        Mv.c += (Gv.c - Mv.c) * omb1;                \
-        V.c += (Gv.c * Gv.c - V.c) * omb2;           \
-        P.c -= (Mv.c * alpha) / (sqrtf(V.c) + eps);
-        FB_ADAM1(x) FB_ADAM1(y) FB_ADAM1(z) FB_ADAM1(w)
-#undef FB_ADAM1
+        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
         reinterpret_cast<float4 *>(p)[q] = P; reinterpret_cast<float4 *>(m)[q] = Mv; reinterpret_cast<float4 *>(v)[q] = V;
         if (q * 4 < OFF_B1) {                                    // W_conv1 changed: refresh its bf16 hi/mid/lo split
             const int idx = (int)q * 4;
@@ -1660,8 +1683,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         const int ndx1 = ((B + 31) / 32) * 50, ndw1 = (50 * (FC / 32) + 7) / 8;
         FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
         const int ndx3 = ((B * 25 + 31) / 32) * 2;
-        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3), dim3(576), 0, st, ndx3, z3, h->params[0], h->dh3, h->h2,
-                                             h->dh2, h->slabs, ss, B);
+        // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
+        const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
+        const int n_adam = (span1 - span0 + 575) / 576;
+        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
+        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam), dim3(576), 0, st, ndx3, z3, h->params[0], h->dh3, h->h2,
+                                             h->dh2, h->slabs, ss, B, n_adam, span);
         const int ndx2 = ((B * 25 + 31) / 32) * 4;
         FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
                                              h->dp1, h->slabs, ss, B);
@@ -1677,8 +1704,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
-            hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G, h->n, h->adam,
-                               (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0]);
+            hipLaunchKernelGGL(adam_kernel, dim3((int)((h->n / 4 - (span1 - span0) + 255) / 256)), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G,
+                               h->n, h->adam, (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0], span0, span1);
         if (p.apply_adam && (only < 0 || only == K_ADAM)) h->wsp_stale[0] = true;
     }
 #undef FB_K
@@ -1733,7 +1760,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     if (!h->adam_ticked) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);     // gradients that did not come from fb_qnet_train_step
     h->adam_ticked = false;
     hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
-                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0]);
+                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0], 0, 0);
     h->wsp_stale[0] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
