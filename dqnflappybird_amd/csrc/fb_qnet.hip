@@ -796,7 +796,11 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     constexpr int ASZ = NS * 512, BSZ = 4 * NS * 64, SLOT = ASZ + BSZ;           // uint4 units
     __shared__ uint4 smem[3 * SLOT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, ks = blockIdx.z;
+    // XCD-aware tile order (consecutive workgroup ids go round the 8 XCDs, each with its own 4 MB L2): XCD x takes K slice
+    // x & 3 and the column tiles of half x >> 2, for every row tile -- 0.6 MB of weights + 2.4 MB of activations per L2
+    // instead of all 4.9 MB of weights behind each one (row-tile-major order: 49 MB through the fabric per 1024 states)
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, nth = a.N >> 7;          // nth = column tiles per half
+    const int ks = xcd & 3, m0 = (w / nth) * 128, n0 = ((xcd >> 2) * nth + w % nth) * 64;
     const int cbase = ks * 12 + (ks < 2 ? ks : 2), count = ks < 2 ? 13 : 12;
     // staging registers as named members (arrays here end up in LDS / scratch: hipcc does not scalarise them)
     struct St { uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2; };
@@ -1630,7 +1634,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     if (sp) {
         C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc};
         Fc1Args af{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, h->hf, stot, maxc, h->FC};
-        const dim3 gc((maxc + 4) / 5), gf((maxc + 127) / 128, h->FC / 64, FC1_SP_KS);
+        const dim3 gc((maxc + 4) / 5), gf(((maxc + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
         if (h->nsplit == 3) {
             FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
             FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
