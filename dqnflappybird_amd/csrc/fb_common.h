@@ -57,5 +57,15 @@ __host__ __device__ static inline fb_u4 fb_philox(uint32_t k0, uint32_t k1, uint
 // (625 words: mt[624], idx) and is advanced by a single wave.
 struct FbMT { uint32_t mt[624]; uint32_t idx; };
 
+// what a draw needs: the generator, the population size n = len(memory) at the time of the call, an error flag
+struct FbSampleCtx { FbMT *mt; int *error; long long n; };
+// random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
+struct FbSampleRider { FbSampleCtx ctx; int k; long long setsize; long long *out; };
+// library-internal (C++ linkage): the env step with the replay sampler as an extra workgroup, and the replay side of it
+int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
+                      int32_t *score, const FbSampleRider *rider, void *stream);
+// the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after ONE more push).  Returns 1 and
+// fills *rider for a uniform memory with the CPython generator, 0 when the sampler cannot ride (PER, other generators).
+int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider);
 void fb_mt_init_genrand_host(FbMT *s, uint32_t seed);
 void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int n);

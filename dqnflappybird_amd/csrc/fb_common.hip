@@ -55,11 +55,24 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
     int rc = fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
     if (rc != FB_OK) return rc;
-    rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
-    if (rc != FB_OK) return rc;
-    if (!train) return fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
+    if (!train) {
+        rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
+        if (rc != FB_OK) return rc;
+        return fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
+    }
     FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
-    rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
+    // random.sample of this step rides in the env launch (same draw as after the push: it only needs the size the memory
+    // will have by then); memories whose sampler cannot ride keep the fused push + sample launch
+    FbSampleRider rider;
+    if (fb_replay_sample_rider(replay, batch, b->idx, &rider)) {
+        rc = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, &rider, stream);
+        if (rc != FB_OK) return rc;
+        rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
+    } else {
+        rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
+        if (rc != FB_OK) return rc;
+        rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
+    }
     if (rc != FB_OK) return rc;
     rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
     if (rc != FB_OK) return rc;

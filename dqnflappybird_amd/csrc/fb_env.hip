@@ -21,6 +21,8 @@
 
 namespace {
 
+#include "fb_sampler.h"           // the replay sampler can ride in the step launch (fb_vec_step)
+
 constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H = 24;
 constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
 constexpr int ENV_THREADS = 512;  // 8 waves: the 80 output rows of an env are rendered 8 at a time
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ frame_bits,
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
-                                                  int32_t *__restrict__ score) {
+                                                  int32_t *__restrict__ score, FbSampleRider rider) {
     __shared__ EnvLds L;
     __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
     __shared__ unsigned long long rowm[OBS];        // columns 0..62 of every output row
@@ -141,11 +143,21 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
     // everything the first env of this workgroup needs from global memory is requested BEFORE the sprite tables are
     // waited for: state, action and the old nibble words travel together with the 25 KB of tables (one round trip
     // instead of three dependent ones)
+    // fb_vec_step: the replay memory's random.sample rides as the FIRST workgroup (one wave of it).  The draw needs the
+    // generator and the memory's size after the push that follows this step, not the frames produced here, and its
+    // ~6 us dependent chain is shorter than this kernel -- in the push launch it was the longest chain of the launch.
+    const int rid = STEP && rider.k ? 1 : 0, nblk = gridDim.x - rid, bid = (int)blockIdx.x - rid;     // workgroup 0 = the rider
+    if (bid < 0) {
+        static_assert(sizeof(EnvLds) >= FB_SAMPLE_LDS_WORDS * 4, "the sampler borrows the sprite tables' LDS");
+        uint32_t *words = reinterpret_cast<uint32_t *>(&L);
+        if (threadIdx.x < 64) sample_cpython_body(rider.ctx, rider.k, rider.setsize, rider.out, words, reinterpret_cast<int *>(words + 624));
+        return;
+    }
     int32_t st0[16];
     int act0 = 0;
     uint32_t nib0[2] = {0u, 0u};
     {
-        const int env = blockIdx.x;                 // < n_envs: the grid never exceeds the env count
+        const int env = bid;                        // < n_envs: the grid never exceeds the env count
 #pragma unroll
         for (int i = 0; i < 16; i++) st0[i] = p.state[(size_t)env * 16 + i];
         if (STEP) act0 = actions[env];
@@ -162,8 +174,8 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int env = blockIdx.x; env < p.n_envs; env += gridDim.x) {
-        const bool first = env == (int)blockIdx.x;
+    for (int env = bid; env < p.n_envs; env += nblk) {
+        const bool first = env == bid;
         int32_t st[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) st[i] = st0[i];
@@ -581,9 +593,17 @@ extern "C" int fb_env_reset(fb_env_t h, void *stream) {
 
 extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
                            uint8_t *terminal, int32_t *score, void *stream) {
+    return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, stream);
+}
+
+int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
+                      int32_t *score, const FbSampleRider *rider, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
-    hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p, actions, frames,
-                       (unsigned long long *)frame_bits, reward, terminal, score);
+    FbSampleRider r;
+    memset(&r, 0, sizeof(r));
+    if (rider) r = *rider;
+    hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid + (r.k ? 1 : 0)), dim3(ENV_THREADS), 0, fb_stream(stream), h->p, actions, frames,
+                       (unsigned long long *)frame_bits, reward, terminal, score, r);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -592,7 +612,7 @@ extern "C" int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits,
     FB_REQUIRE(h && (frames || frame_bits), "fb_env_observe: NULL argument");
     hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p,
                        (const uint8_t *)nullptr, frames, (unsigned long long *)frame_bits, (float *)nullptr,
-                       (uint8_t *)nullptr, (int32_t *)nullptr);
+                       (uint8_t *)nullptr, (int32_t *)nullptr, FbSampleRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

@@ -50,6 +50,9 @@ struct ReplayParams {
     uint32_t seed_lo, seed_hi;
 };
 
+#include "fb_sampler.h"
+static_assert(MAXB == FB_SAMPLE_MAXB, "sampler batch limit");
+
 __device__ __forceinline__ size_t frame_off(const ReplayParams &P, long long f, int e) {
     if (f < 0) f = 0;                                   // setInitState: the first frame four times
     return ((size_t)(f % P.t_f) * P.n_envs + e) * WORDS;
@@ -156,126 +159,17 @@ __global__ __launch_bounds__(256) void gather_kernel(ReplayParams P, long long s
     }
 }
 
-// ------------------------------------------------------------------ MT19937 on one wave
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
-    return y;
-}
-
-// Regenerate the 624-word block with 64 lanes.  Chunks go in increasing order; inside a chunk every
-// lane reads before any lane writes, which preserves the sequential algorithm's dependencies
-// (new values are needed at distance 227 behind, old values at distance 1 ahead).
-__device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
-    for (int base = 0; base < 624; base += 64) {
-        const int i = base + lane;
-        uint32_t v = 0;
-        if (i < 624) {
-            const uint32_t y = (mt[i] & 0x80000000u) | (mt[i == 623 ? 0 : i + 1] & 0x7fffffffu);
-            v = mt[i + 397 < 624 ? i + 397 : i + 397 - 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (i < 624) mt[i] = v;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// random.sample(range(n), k) on one wave.  Set path (n > setsize, the normal case): the wave tempers up to
-// 64 state words at once, ballots the ones below n and walks only those, in stream order, testing each
-// against the already selected values with one wave-wide compare -- no per-word LDS round trip.  Words are
-// consumed exactly like CPython consumes them (every getrandbits call, also rejected / duplicate ones, up
-// to and including the word that completed the sample).  Pool path (n <= setsize): the modulus shrinks
-// with every draw, so it stays word-serial.  Lane (i & 63) keeps result i in register slot i >> 6.
-__device__ __forceinline__ void sample_cpython_body(const ReplayParams &P, int k, long long setsize, long long steps,
-                                                    long long *__restrict__ out, uint32_t *mt, int *pool) {
-    const int lane = threadIdx.x;
-    // the whole block is fetched beside the cursor (one round trip; a window that depends on the cursor would be two);
-    // it is written back only when this call regenerated it -- otherwise the cursor alone
-    for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
-    uint32_t idx = P.mt->idx;
-    bool regenerated = false;
+// ------------------------------------------------------------------ MT19937 on one wave + random.sample: fb_sampler.h
+__device__ __forceinline__ FbSampleCtx sample_ctx(const ReplayParams &P, long long steps) {
     const long long total = steps * P.n_envs;
-    const long long n = total < P.cap ? total : P.cap;
-    if (k > n || k > MAXB) {
-        if (lane == 0) P.dev->error = 2;                // "Sample larger than population"
-        for (int i = lane; i < k; i += 64) out[i] = 0;
-        return;
-    }
-    __syncthreads();
-    long long sel[4] = {-1, -1, -1, -1};
-    if (n > setsize) {
-        const int shift = __builtin_clz((uint32_t)n);   // 32 - n.bit_length()
-        int i = 0;
-        if (k <= 64) {
-            // Optimistic path: if the next <= 64 words hold k candidates below n and those are pairwise distinct (all but
-            // ~k^2 / 2n of the calls), they ARE the sample, in stream order -- decided with a ballot, a rank and one round
-            // of wave shuffles instead of k dependent iterations.  Otherwise nothing has been consumed and the loop runs.
-            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
-            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
-            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
-            const bool valid = lane < take && w < (uint32_t)n;
-            const unsigned long long mask = __ballot(valid);
-            if (__popcll(mask) >= k) {
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                if (valid && rank < k) pool[rank] = (int)w;
-                __syncthreads();                        // one wave per workgroup: orders the LDS writes before the reads
-                const uint32_t c = lane < k ? (uint32_t)pool[lane] : (0x80000000u | (uint32_t)lane);   // distinct sentinels past k
-                bool dup = false;
-                for (int d = 1; d < 64; d++) dup |= (uint32_t)__shfl((int)c, (lane + d) & 63) == c;
-                if (!__any(dup)) {
-                    if (lane < k) sel[0] = (long long)c;
-                    idx += __builtin_ctzll(__ballot(valid && rank == k - 1)) + 1;     // up to and including the k-th candidate
-                    i = k;
-                }
-            }
-        }
-        while (i < k) {
-            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
-            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
-            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
-            unsigned long long mask = __ballot(lane < take && w < (uint32_t)n);
-            int consumed = take;
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const long long c = (long long)__shfl(w, l);
-                bool dup = false;
-#pragma unroll
-                for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
-                if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
-                if (lane == (i & 63)) sel[i >> 6] = c;
-                if (++i == k) { consumed = l + 1; break; }
-            }
-            idx += consumed;
-        }
-    } else {
-        for (int i = lane; i < (int)n; i += 64) pool[i] = i;
-        __syncthreads();
-        for (int i = 0; i < k; i++) {
-            const uint32_t m = (uint32_t)(n - i);
-            const int nbits = 32 - __builtin_clz(m);
-            uint32_t r;
-            do {                                        // _randbelow_with_getrandbits
-                if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
-                r = mt_temper(mt[idx++]) >> (32 - nbits);
-            } while (r >= m);
-            const long long res = pool[r];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) pool[r] = pool[m - 1];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == (i & 63)) sel[i >> 6] = res;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
-    if (regenerated) for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];       // the block only changes when it is regenerated
-    if (lane == 0) P.mt->idx = idx;
+    return FbSampleCtx{P.mt, &P.dev->error, total < P.cap ? total : P.cap};
 }
 
 __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
                                                             long long *__restrict__ out) {
     __shared__ uint32_t mt[624];
     __shared__ int pool[1100];
-    sample_cpython_body(P, k, setsize, P.dev->steps, out, mt, pool);
+    sample_cpython_body(sample_ctx(P, P.dev->steps), k, setsize, out, mt, pool);
 }
 
 // fb_replay_push_sample: Memory append + random.sample in ONE launch.  The sample only needs the size the
@@ -288,7 +182,7 @@ __global__ __launch_bounds__(64) void push_sample_kernel(ReplayParams P, long lo
                                                          long long *__restrict__ out) {
     __shared__ uint32_t mt[624];
     __shared__ int pool[1100];
-    if (blockIdx.x == gridDim.x - 1) { sample_cpython_body(P, k, setsize, steps + 1, out, mt, pool); return; }
+    if (blockIdx.x == gridDim.x - 1) { sample_cpython_body(sample_ctx(P, steps + 1), k, setsize, out, mt, pool); return; }
     const int lane = threadIdx.x;
     for (int e = blockIdx.x; e < P.n_envs; e += gridDim.x - 1) {
         unsigned long long *dst = P.bits + frame_off(P, steps + 1, e);
@@ -763,6 +657,15 @@ extern "C" int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const
     FB_LAUNCH_CHECK();
     h->host_steps += 1;
     return FB_OK;
+}
+
+int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider) {
+    const ReplayParams &P = h->P;
+    if (P.kind != FB_REPLAY_UNIFORM || P.rng_kind != FB_RNG_CPYTHON || batch < 1 || batch > MAXB || !idx) return 0;
+    const long long total = (h->host_steps + 1) * P.n_envs;
+    rider->ctx = FbSampleCtx{P.mt, &P.dev->error, total < P.cap ? total : P.cap};
+    rider->k = batch; rider->setsize = cpython_setsize(batch); rider->out = (long long *)idx;
+    return 1;
 }
 
 extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream) {

@@ -1,0 +1,121 @@
+// MT19937 on one wave and CPython's random.sample on top of it -- device code shared by the replay kernels
+// (fb_replay.hip) and the env step kernel, which can carry the sampler as a rider (fb_env.hip, fb_vec_step).
+// Included inside each translation unit's anonymous namespace.
+#pragma once
+
+constexpr int FB_SAMPLE_MAXB = 256;          // indices per draw (4 register slots x 64 lanes)
+constexpr int FB_SAMPLE_LDS_WORDS = 624 + 1100;      // mt[624] + pool[1100]
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+
+// Regenerate the 624-word block with 64 lanes.  Chunks go in increasing order; inside a chunk every
+// lane reads before any lane writes, which preserves the sequential algorithm's dependencies
+// (new values are needed at distance 227 behind, old values at distance 1 ahead).
+__device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
+    for (int base = 0; base < 624; base += 64) {
+        const int i = base + lane;
+        uint32_t v = 0;
+        if (i < 624) {
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[i == 623 ? 0 : i + 1] & 0x7fffffffu);
+            v = mt[i + 397 < 624 ? i + 397 : i + 397 - 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i < 624) mt[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// random.sample(range(n), k) on one wave.  Set path (n > setsize, the normal case): the wave tempers up to
+// 64 state words at once, ballots the ones below n and walks only those, in stream order, testing each
+// against the already selected values with one wave-wide compare -- no per-word LDS round trip.  Words are
+// consumed exactly like CPython consumes them (every getrandbits call, also rejected / duplicate ones, up
+// to and including the word that completed the sample).  Pool path (n <= setsize): the modulus shrinks
+// with every draw, so it stays word-serial.  Lane (i & 63) keeps result i in register slot i >> 6.
+__device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k, long long setsize,
+                                                    long long *__restrict__ out, uint32_t *mt, int *pool) {
+    const int lane = threadIdx.x;
+    // the whole block is fetched beside the cursor (one round trip; a window that depends on the cursor would be two);
+    // it is written back only when this call regenerated it -- otherwise the cursor alone
+    for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
+    uint32_t idx = P.mt->idx;
+    bool regenerated = false;
+    const long long n = P.n;
+    if (k > n || k > FB_SAMPLE_MAXB) {
+        if (lane == 0) *P.error = 2;                    // "Sample larger than population"
+        for (int i = lane; i < k; i += 64) out[i] = 0;
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    long long sel[4] = {-1, -1, -1, -1};
+    if (n > setsize) {
+        const int shift = __builtin_clz((uint32_t)n);   // 32 - n.bit_length()
+        int i = 0;
+        if (k <= 64) {
+            // Optimistic path: if the next <= 64 words hold k candidates below n and those are pairwise distinct (all but
+            // ~k^2 / 2n of the calls), they ARE the sample, in stream order -- decided with a ballot, a rank and one round
+            // of wave shuffles instead of k dependent iterations.  Otherwise nothing has been consumed and the loop runs.
+            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
+            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
+            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
+            const bool valid = lane < take && w < (uint32_t)n;
+            const unsigned long long mask = __ballot(valid);
+            if (__popcll(mask) >= k) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                if (valid && rank < k) pool[rank] = (int)w;
+                __builtin_amdgcn_wave_barrier();        // one wave: LDS executes its writes before its reads; this pins the order
+                const uint32_t c = lane < k ? (uint32_t)pool[lane] : (0x80000000u | (uint32_t)lane);   // distinct sentinels past k
+                bool dup = false;
+                for (int d = 1; d < 64; d++) dup |= (uint32_t)__shfl((int)c, (lane + d) & 63) == c;
+                if (!__any(dup)) {
+                    if (lane < k) sel[0] = (long long)c;
+                    idx += __builtin_ctzll(__ballot(valid && rank == k - 1)) + 1;     // up to and including the k-th candidate
+                    i = k;
+                }
+            }
+        }
+        while (i < k) {
+            if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
+            const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
+            const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
+            unsigned long long mask = __ballot(lane < take && w < (uint32_t)n);
+            int consumed = take;
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const long long c = (long long)__shfl(w, l);
+                bool dup = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
+                if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
+                if (lane == (i & 63)) sel[i >> 6] = c;
+                if (++i == k) { consumed = l + 1; break; }
+            }
+            idx += consumed;
+        }
+    } else {
+        for (int i = lane; i < (int)n; i += 64) pool[i] = i;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < k; i++) {
+            const uint32_t m = (uint32_t)(n - i);
+            const int nbits = 32 - __builtin_clz(m);
+            uint32_t r;
+            do {                                        // _randbelow_with_getrandbits
+                if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
+                r = mt_temper(mt[idx++]) >> (32 - nbits);
+            } while (r >= m);
+            const long long res = pool[r];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) pool[r] = pool[m - 1];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == (i & 63)) sel[i >> 6] = res;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
+    if (regenerated) for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];       // the block only changes when it is regenerated
+    if (lane == 0) P.mt->idx = idx;
+}
+

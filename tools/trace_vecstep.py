@@ -1,0 +1,17 @@
+"""The loop bench.py times (fb_vec_step: act -> env -> push[+sample] -> gather[+draw ahead] -> train, one host call per
+step), 150 steps -- target for rocprofv3 --kernel-trace; tools/trace_gaps.py CSV 400 then gives the in-situ duration of
+every kernel of a step and the idle gap in front of it."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+n, B = 1024, 32
+env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n), QNet(max_batch=n)
+replay.seed(0, "cpython")
+net.init_params(0)
+nib = env.track_state()
+env.observe(); replay.reset(env.frame_bits)
+one = VecStep(env, replay, net, B, "dqn")
+for step in range(150):
+    one(0.03, seed=0, step=step)
+torch.cuda.synchronize()
