@@ -61,9 +61,16 @@ struct FbMT { uint32_t mt[624]; uint32_t idx; };
 struct FbSampleCtx { FbMT *mt; int *error; long long n; };
 // random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
 struct FbSampleRider { FbSampleCtx ctx; int k; long long setsize; long long *out; };
+// Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
+// into the ring slot of the coming push (bits: slot of env 0's frame, +100 words per env; act / rew / term: row of the
+// step, +1 per env; bits == NULL: no rider).  steps_dev receives steps_new (the device mirror of the push counter).
+struct FbPushRider { unsigned long long *bits; uint8_t *act; float *rew; uint8_t *term; long long *steps_dev; long long steps_new; };
 // library-internal (C++ linkage): the env step with the replay sampler as an extra workgroup, and the replay side of it
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
-                      int32_t *score, const FbSampleRider *rider, void *stream);
+                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, void *stream);
+// the rider for "fb_replay_push" of a uniform memory (returns 1, fills *push and COUNTS the push: the env launch that
+// carries it must follow), 0 for a prioritized memory (its tree update needs its own launches)
+int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push);
 // the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after ONE more push).  Returns 1 and
 // fills *rider for a uniform memory with the CPython generator, 0 when the sampler cannot ride (PER, other generators).
 int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider);

@@ -55,25 +55,22 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
     int rc = fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
     if (rc != FB_OK) return rc;
-    if (!train) {
-        rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
-        if (rc != FB_OK) return rc;
-        return fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
-    }
-    FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
-    // random.sample of this step rides in the env launch (same draw as after the push: it only needs the size the memory
-    // will have by then); memories whose sampler cannot ride keep the fused push + sample launch
-    FbSampleRider rider;
-    if (fb_replay_sample_rider(replay, batch, b->idx, &rider)) {
-        rc = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, &rider, stream);
-        if (rc != FB_OK) return rc;
-        rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
-    } else {
-        rc = fb_env_step(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, stream);
-        if (rc != FB_OK) return rc;
-        rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
-    }
+    // Riders of the env launch (uniform memory): random.sample of this step -- it only needs the size the memory will have
+    // after the push, not the frames -- and the push itself: every env workgroup stores its transition straight into the
+    // ring.  Memories that cannot ride keep their own launches (same results).
+    if (train) FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
+    FbSampleRider srider;
+    FbPushRider prider;
+    const int have_s = train ? fb_replay_sample_rider(replay, batch, b->idx, &srider) : 0;      // before the push is counted
+    const int have_p = fb_replay_begin_push_rider(replay, &prider);
+    rc = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, have_s ? &srider : nullptr,
+                           have_p ? &prider : nullptr, stream);
     if (rc != FB_OK) return rc;
+    if (!have_p) {
+        if (train && !have_s) rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
+        else rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
+    } else if (train && !have_s) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
+    if (rc != FB_OK || !train) return rc;
     rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
     if (rc != FB_OK) return rc;
     return fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, nullptr, gamma, b->loss, nullptr, nullptr, b->flat_grad,

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ frame_bits,
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
-                                                  int32_t *__restrict__ score, FbSampleRider rider) {
+                                                  int32_t *__restrict__ score, FbSampleRider rider, FbPushRider push) {
     __shared__ EnvLds L;
     __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
     __shared__ unsigned long long rowm[OBS];        // columns 0..62 of every output row
@@ -240,6 +240,10 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                 reward[env] = bad ? 0.f : rew;
                 terminal[env] = (uint8_t)term;
                 score[env] = score_ret;
+                if (push.bits) {         // Memory append (fb_replay_push) riding in this launch: the transition's scalars
+                    push.act[env] = first ? (uint8_t)act0 : actions[env]; push.rew[env] = bad ? 0.f : rew; push.term[env] = (uint8_t)term;
+                    if (env == 0) *push.steps_dev = push.steps_new;
+                }
                 if (bad) atomicAdd(p.err_count, 1ull);
                 if (p.stats) {           // device-side counters behind the reference's GAME_TIMES / score log lines: no host sync per step
                     if (term) { atomicAdd(&p.stats[0], 1ull); atomicAdd(&p.stats[1], (unsigned long long)score_ret); atomicMax(&p.stats[2], (unsigned long long)score_ret); }
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         }
         __syncthreads();
         if (frame_bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) frame_bits[(size_t)env * 100 + w] = fw[w];
+        if (STEP && push.bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) push.bits[(size_t)env * 100 + w] = fw[w];   // ... and its frame
         if (p.nib) {
             // the agent's 4-frame stack (BrainDQN.py:68,238-239: newest last, never reset) as one nibble per pixel:
             // bit f of a pixel's nibble = frame f of the stack; a step shifts the nibbles down and puts the new
@@ -593,17 +598,19 @@ extern "C" int fb_env_reset(fb_env_t h, void *stream) {
 
 extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
                            uint8_t *terminal, int32_t *score, void *stream) {
-    return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, stream);
+    return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, nullptr, stream);
 }
 
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
-                      int32_t *score, const FbSampleRider *rider, void *stream) {
+                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
     FbSampleRider r;
-    memset(&r, 0, sizeof(r));
+    FbPushRider q;
+    memset(&r, 0, sizeof(r)); memset(&q, 0, sizeof(q));
     if (rider) r = *rider;
+    if (push) q = *push;
     hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid + (r.k ? 1 : 0)), dim3(ENV_THREADS), 0, fb_stream(stream), h->p, actions, frames,
-                       (unsigned long long *)frame_bits, reward, terminal, score, r);
+                       (unsigned long long *)frame_bits, reward, terminal, score, r, q);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -612,7 +619,7 @@ extern "C" int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits,
     FB_REQUIRE(h && (frames || frame_bits), "fb_env_observe: NULL argument");
     hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p,
                        (const uint8_t *)nullptr, frames, (unsigned long long *)frame_bits, (float *)nullptr,
-                       (uint8_t *)nullptr, (int32_t *)nullptr, FbSampleRider{});
+                       (uint8_t *)nullptr, (int32_t *)nullptr, FbSampleRider{}, FbPushRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

@@ -659,6 +659,18 @@ extern "C" int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const
     return FB_OK;
 }
 
+int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
+    ReplayParams &P = h->P;
+    if (P.kind != FB_REPLAY_UNIFORM) return 0;
+    const long long steps = h->host_steps;               // push_kernel: frame steps + 1, meta row steps
+    push->bits = P.bits + (size_t)((steps + 1) % P.t_f) * P.n_envs * WORDS;
+    const size_t mo = (size_t)(steps % P.t_f) * P.n_envs;
+    push->act = P.act + mo; push->rew = P.rew + mo; push->term = P.term + mo;
+    push->steps_dev = &P.dev->steps; push->steps_new = steps + 1;
+    h->host_steps += 1;
+    return 1;
+}
+
 int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider) {
     const ReplayParams &P = h->P;
     if (P.kind != FB_REPLAY_UNIFORM || P.rng_kind != FB_RNG_CPYTHON || batch < 1 || batch > MAXB || !idx) return 0;
