@@ -61,13 +61,25 @@ struct FbMT { uint32_t mt[624]; uint32_t idx; };
 struct FbSampleCtx { FbMT *mt; int *error; long long n; };
 // random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
 struct FbSampleRider { FbSampleCtx ctx; int k; long long setsize; long long *out; };
+// fc2 / dueling head + epsilon-greedy action of one state from the fc1 partial sums (fb_head.h): the acting path's last
+// kernel, which fb_vec_step lets ride in the env step launch (every env workgroup computes its own action first).
+struct NetOff { int bf1, wv, bv, wq, bq, n; };
+struct HeadCore {
+    const float *hf; int stot, nks; float *q; int FC, A, dueling; NetOff off;
+    uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
+};
+struct FbHeadRider { HeadCore c; const float *params; int on; };
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
 // into the ring slot of the coming push (bits: slot of env 0's frame, +100 words per env; act / rew / term: row of the
 // step, +1 per env; bits == NULL: no rider).  steps_dev receives steps_new (the device mirror of the push counter).
 struct FbPushRider { unsigned long long *bits; uint8_t *act; float *rew; uint8_t *term; long long *steps_dev; long long steps_new; };
 // library-internal (C++ linkage): the env step with the replay sampler as an extra workgroup, and the replay side of it
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
-                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, void *stream);
+                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream);
+int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
+// fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
+int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
+                          uint8_t *actions, FbHeadRider *head, void *stream);
 // the rider for "fb_replay_push" of a uniform memory (returns 1, fills *push and COUNTS the push: the env launch that
 // carries it must follow), 0 for a prioritized memory (its tree update needs its own launches)
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push);

@@ -1,4 +1,5 @@
 // fb_common.hip -- error channel, version, host-side MT19937 seeding.
+#include <stdlib.h>
 #include "fb_common.h"
 
 thread_local char fb_err_buf[512] = "";
@@ -53,7 +54,13 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     FB_REQUIRE(env && replay && net && b, "fb_vec_step: NULL handle");
     FB_REQUIRE(b->nib && b->actions && b->frame_bits && b->reward && b->terminal && b->score, "fb_vec_step: NULL env buffer");
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
-    int rc = fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
+    // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
+    // every env has a workgroup of its own there
+    FbHeadRider hrider;
+    static const bool head_rides = !(getenv("FB_VEC_HEAD_RIDER") && atoi(getenv("FB_VEC_HEAD_RIDER")) == 0);      // tuning knob
+    const int have_h = head_rides && fb_env_can_carry_head(env);
+    int rc = have_h ? fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, stream)
+                    : fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
     if (rc != FB_OK) return rc;
     // Riders of the env launch (uniform memory): random.sample of this step -- it only needs the size the memory will have
     // after the push, not the frames -- and the push itself: every env workgroup stores its transition straight into the
@@ -64,7 +71,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     const int have_s = train ? fb_replay_sample_rider(replay, batch, b->idx, &srider) : 0;      // before the push is counted
     const int have_p = fb_replay_begin_push_rider(replay, &prider);
     rc = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, have_s ? &srider : nullptr,
-                           have_p ? &prider : nullptr, stream);
+                           have_p ? &prider : nullptr, have_h ? &hrider : nullptr, stream);
     if (rc != FB_OK) return rc;
     if (!have_p) {
         if (train && !have_s) rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);

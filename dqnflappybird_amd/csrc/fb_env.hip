@@ -22,6 +22,7 @@
 namespace {
 
 #include "fb_sampler.h"           // the replay sampler can ride in the step launch (fb_vec_step)
+#include "fb_head.h"              // ... and so can the acting path's head (fc2 + epsilon-greedy action of this env)
 
 constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H = 24;
 constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
@@ -134,12 +135,14 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ frame_bits,
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
-                                                  int32_t *__restrict__ score, FbSampleRider rider, FbPushRider push) {
+                                                  int32_t *__restrict__ score, FbSampleRider rider, FbPushRider push,
+                                                  FbHeadRider head) {
     __shared__ EnvLds L;
     __shared__ unsigned long long fw[100];          // the frame being assembled, 1 bit / pixel
     __shared__ unsigned long long rowm[OBS];        // columns 0..62 of every output row
     __shared__ int slow_rows[OBS];
     __shared__ int nslow;
+    __shared__ int act_mail;                        // the head rider's action for the other waves
     // everything the first env of this workgroup needs from global memory is requested BEFORE the sprite tables are
     // waited for: state, action and the old nibble words travel together with the 25 KB of tables (one round trip
     // instead of three dependent ones)
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         const int env = bid;                        // < n_envs: the grid never exceeds the env count
 #pragma unroll
         for (int i = 0; i < 16; i++) st0[i] = p.state[(size_t)env * 16 + i];
-        if (STEP) act0 = actions[env];
+        if (STEP && !head.on) act0 = actions[env];
         if (STEP && p.nib) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nib + (size_t)env * FB_NIB_STRIDE);
             const int w1 = threadIdx.x + ENV_THREADS < 800 ? threadIdx.x + ENV_THREADS : 0;
@@ -170,8 +173,15 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
         for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += ENV_THREADS) dst[i] = src[i];
+        // fb_vec_step: the acting path's head rides here -- wave 0 turns this env's fc1 partial sums into its Q values and
+        // its epsilon-greedy action (head_one: head_kernel's own code) while the tables above are on their way
+        if (STEP && head.on && threadIdx.x < 64) {
+            const int a = head_one(head.c, head.params, env, threadIdx.x);
+            if (threadIdx.x == 0) act_mail = a;             // handed to the other waves through LDS
+        }
     }
     __syncthreads();
+    if (STEP && head.on) act0 = act_mail;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     for (int env = bid; env < p.n_envs; env += nblk) {
@@ -598,19 +608,24 @@ extern "C" int fb_env_reset(fb_env_t h, void *stream) {
 
 extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward,
                            uint8_t *terminal, int32_t *score, void *stream) {
-    return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, nullptr, stream);
+    return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, nullptr, nullptr, stream);
 }
 
+int fb_env_can_carry_head(fb_env_t h) { return h && h->grid == h->p.n_envs; }
+
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
-                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, void *stream) {
+                      int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
+    FB_REQUIRE(!head || h->grid == h->p.n_envs, "fb_env_step: the head rider needs one workgroup per env");
     FbSampleRider r;
     FbPushRider q;
-    memset(&r, 0, sizeof(r)); memset(&q, 0, sizeof(q));
+    FbHeadRider hd;
+    memset(&r, 0, sizeof(r)); memset(&q, 0, sizeof(q)); memset(&hd, 0, sizeof(hd));
     if (rider) r = *rider;
     if (push) q = *push;
+    if (head) hd = *head;
     hipLaunchKernelGGL(env_kernel<true>, dim3(h->grid + (r.k ? 1 : 0)), dim3(ENV_THREADS), 0, fb_stream(stream), h->p, actions, frames,
-                       (unsigned long long *)frame_bits, reward, terminal, score, r, q);
+                       (unsigned long long *)frame_bits, reward, terminal, score, r, q, hd);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -619,7 +634,7 @@ extern "C" int fb_env_observe(fb_env_t h, uint8_t *frames, uint64_t *frame_bits,
     FB_REQUIRE(h && (frames || frame_bits), "fb_env_observe: NULL argument");
     hipLaunchKernelGGL(env_kernel<false>, dim3(h->grid), dim3(ENV_THREADS), 0, fb_stream(stream), h->p,
                        (const uint8_t *)nullptr, frames, (unsigned long long *)frame_bits, (float *)nullptr,
-                       (uint8_t *)nullptr, (int32_t *)nullptr, FbSampleRider{}, FbPushRider{});
+                       (uint8_t *)nullptr, (int32_t *)nullptr, FbSampleRider{}, FbPushRider{}, FbHeadRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

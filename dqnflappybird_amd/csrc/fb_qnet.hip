@@ -26,9 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int OFF_W1 = 0, OFF_B1 = 8192, OFF_W2 = 8224, OFF_B2 = 40992, OFF_W3 = 41056, OFF_B3 = 77920,
               OFF_WF1 = 77984;
 constexpr int CONV_PARAMS = OFF_WF1;         // everything in front of W_fc1
-constexpr int MAXA = 8, MAXTB = 256;
+#include "fb_head.h"               // MAXA, FC1_KS, sel4, head_one
+constexpr int MAXTB = 256;
 
-struct NetOff { int bf1, wv, bv, wq, bq, n; };
 
 struct Slice { const float *params; const uint8_t *states; int s_off, count; const uint16_t *w1s; };
 struct Slices { Slice s[3]; };
@@ -90,10 +90,6 @@ __device__ __forceinline__ void reduce_rows(const f32x16 &acc, float *red, int w
 // that uses it, which brings the vmcnt(0)-per-load behaviour back
 __device__ __forceinline__ void keep(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void keep(int &x) { asm volatile("" : "+v"(x)); }
-
-__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
 
 // KH MFMAs: A from a contiguous run of KH floats (or zeros), B from a column with stride bstride
 template <int KH>
@@ -391,8 +387,7 @@ __global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *
 // fc1 1600xFC: the K = 1600 reduction is split over FC1_KS = 5 workgroups x 8 waves x 40 k, so every wave
 // issues its 40 operand loads at once and runs 20 MFMAs.  The 5 partial sums stay separate
 // (hfp[ks][sample][FC], no bias / relu yet): the two consumers (head_kernel, loss_head_kernel) add them in
-// a fixed order -- "reduce in the consumer's prologue" instead of one more launch.
-constexpr int FC1_KS = 5;
+// a fixed order -- "reduce in the consumer's prologue" instead of one more launch.  (FC1_KS: fb_head.h)
 
 __global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
                                                   int stot) {
@@ -908,10 +903,7 @@ __device__ __forceinline__ float fc1_out(const float *__restrict__ hfp, int stot
 }
 
 // fc2 / dueling head (+ epsilon-greedy action for the acting path); one wave per sample
-struct HeadArgs {
-    Slices sl; int nslices; const float *hf; int stot, nks; float *q; int FC, A, dueling; NetOff off;
-    uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
-};
+struct HeadArgs { Slices sl; int nslices; HeadCore c; };
 
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -923,55 +915,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
         sidx -= H.sl.s[z].count;
     }
     if (smp < 0) return;
-    float acc[MAXA + 1];
-#pragma unroll
-    for (int a = 0; a <= MAXA; a++) acc[a] = 0.f;
-    // a lane takes 4 consecutive units per round (FC % 128 == 0): the nks partial sums and the bias arrive as float4,
-    // all rounds' loads in flight together; the per-unit arithmetic and its order are those of fc1_out
-    for (int j0 = 4 * lane; j0 < H.FC; j0 += 256) {
-        float4 t[FC1_KS];
-#pragma unroll
-        for (int ks = 0; ks < FC1_KS; ks++)
-            t[ks] = sel4(ks < H.nks, *reinterpret_cast<const float4 *>(H.hf + ((size_t)(ks < H.nks ? ks : 0) * H.stot + smp) * H.FC + j0));
-        const float4 bv = *reinterpret_cast<const float4 *>(P + H.off.bf1 + j0);
-        float4 v = t[0];
-#pragma unroll
-        for (int ks = 1; ks < FC1_KS; ks++) { v.x += t[ks].x; v.y += t[ks].y; v.z += t[ks].z; v.w += t[ks].w; }
-        const float x4[4] = {fmaxf(v.x + bv.x, 0.f), fmaxf(v.y + bv.y, 0.f), fmaxf(v.z + bv.z, 0.f), fmaxf(v.w + bv.w, 0.f)};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int jj = j0 + e;
-#pragma unroll
-            for (int a = 0; a < MAXA; a++) if (a < H.A) acc[a] = fmaf(x4[e], P[H.off.wq + jj * H.A + a], acc[a]);
-            if (H.dueling) acc[MAXA] = fmaf(x4[e], P[H.off.wv + jj], acc[MAXA]);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a <= MAXA; a++)
-        for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o);
-    float qv[MAXA];
-    float mean = 0.f;
-#pragma unroll
-    for (int a = 0; a < MAXA; a++) { qv[a] = a < H.A ? acc[a] + P[H.off.bq + a] : 0.f; if (a < H.A) mean += qv[a]; }
-    if (H.dueling) {                                             // Q = V + (A - mean_a A)
-        const float V = acc[MAXA] + P[H.off.bv];
-        mean /= (float)H.A;
-#pragma unroll
-        for (int a = 0; a < MAXA; a++) qv[a] = V + (qv[a] - mean);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < MAXA; a++) if (a < H.A) H.q[(size_t)smp * H.A + a] = qv[a];
-        if (H.actions) {                                         // BrainDQN.py:103-108
-            int best = 0;
-#pragma unroll
-            for (int a = 1; a < MAXA; a++) if (a < H.A && qv[a] > qv[best]) best = a;       // np.argmax: first maximum
-            const fb_u4 o = fb_philox(H.seed_lo, H.seed_hi, (uint32_t)smp, H.step_lo, FB_STREAM_EPS, H.step_hi);
-            const float u = (float)(o.x >> 8) * (1.0f / 16777216.0f);                      // random.random()
-            if (u <= H.epsilon) best = (int)(((unsigned long long)o.y * (unsigned)H.A) >> 32);   // randrange(A)
-            H.actions[smp] = (uint8_t)best;
-        }
-    }
+    head_one(H.c, P, smp, lane);
 }
 
 // ================================================================== loss + head backward
@@ -1597,6 +1541,7 @@ struct Plan {
     bool train;                              // forward only when false
     int algo, B; const uint8_t *s, *a, *t; const float *r, *isw; double gamma;
     float *loss, *abs_err, *y, *G; bool apply_adam, tick;
+    FbHeadRider *head_rider;                 // acting path: describe the head work instead of launching it (fb_vec_step)
 };
 
 static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
@@ -1657,11 +1602,14 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     }
     FB_K(K_HEAD) {
         HeadArgs H;
-        H.sl = p.sl; H.nslices = p.ns; H.hf = h->hf; H.stot = stot; H.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : FC1_KS; H.q = h->q; H.FC = h->FC; H.A = h->A;
-        H.dueling = h->arch == FB_ARCH_DUELING; H.off = h->off; H.actions = p.actions; H.epsilon = p.epsilon;
-        H.seed_lo = (uint32_t)p.seed; H.seed_hi = (uint32_t)(p.seed >> 32);
-        H.step_lo = (uint32_t)p.step; H.step_hi = (uint32_t)(p.step >> 32);
-        hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
+        H.sl = p.sl; H.nslices = p.ns;
+        HeadCore &C = H.c;
+        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : FC1_KS; C.q = h->q; C.FC = h->FC; C.A = h->A;
+        C.dueling = h->arch == FB_ARCH_DUELING; C.off = h->off; C.actions = p.actions; C.epsilon = p.epsilon;
+        C.seed_lo = (uint32_t)p.seed; C.seed_hi = (uint32_t)(p.seed >> 32);
+        C.step_lo = (uint32_t)p.step; C.step_hi = (uint32_t)(p.step >> 32);
+        if (p.head_rider) { p.head_rider->c = C; p.head_rider->params = p.sl.s[0].params; p.head_rider->on = 1; }   // rides in the env launch
+        else hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
     }
     if (p.train) {
         const int B = p.B, FC = h->FC;
@@ -1756,6 +1704,17 @@ extern "C" int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, fl
     if (rc != FB_OK) return rc;
     if (q) FB_CHECK_HIP(hipMemcpyAsync(q, h->q, sizeof(float) * (size_t)n * h->A, hipMemcpyDeviceToDevice, fb_stream(stream)));
     return FB_OK;
+}
+
+int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
+                          uint8_t *actions, FbHeadRider *head, void *stream) {
+    FB_REQUIRE(h && nib_states && actions && head, "fb_qnet_act_nib_rider: NULL argument");
+    FB_REQUIRE(n >= 1 && n <= 3 * h->max_batch, "fb_qnet_act_nib: n %d exceeds 3*max_batch", n);
+    Plan p = forward_plan(h, 0, nib_states, n);
+    p.nib = true;
+    p.actions = actions; p.epsilon = epsilon; p.seed = seed; p.step = step;
+    p.head_rider = head;
+    return run_plan(h, p, -1, fb_stream(stream));
 }
 
 extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream) {
