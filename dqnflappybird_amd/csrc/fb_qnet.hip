@@ -936,44 +936,87 @@ struct LossArgs {
 // grid = FC / 64 workgroups.  Every workgroup recomputes the B targets (cheap), workgroup 0 also publishes
 // loss / abs_err / y, the output-bias gradients and the Adam tick.  Thread (jl, bg) owns unit j and every
 // 4th sample; the 4 partial sums per unit are added in a fixed order.
-__global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
-    __shared__ float dadv[MAXTB][MAXA];
-    __shared__ float dv[MAXTB];
-    __shared__ float lterm[MAXTB];
-    __shared__ float part[4][64][MAXA + 2];
-    const int tid = threadIdx.x, B = L.B, A = L.A;
+// ONE round trip to memory: the unit's parameters and the fc1 partial sums of its first 8 samples (all of them at
+// B <= 32) are requested at the top, together with the Q values / rewards / actions of the target computation --
+// nothing is loaded behind the barrier, and no load sits under a branch (clamped addresses + selects; AT = the
+// number of actions at compile time, MAXA = read it from L.A).
+template <int AT>
+__device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[MAXA], float *dv, float *lterm, float (*part)[64][MAXA + 2]) {
+    const int tid = threadIdx.x, B = L.B, A = AT == MAXA ? L.A : AT;
     const bool lead = blockIdx.x == 0;
-    if (tid < B) {
-        const float *qs = L.q + (size_t)tid * A;
-        const float *qn = L.q + (size_t)(B + tid) * A;          // DQN: online(s'); Nature/PER: target(s'); Double: online(s')
+    const float *P = L.params;
+    const int jl = tid & 63, bg = tid >> 6, jj = blockIdx.x * 64 + jl;
+    // ---- everything this thread needs from memory
+    float gw[AT], wrow[AT], gv = 0.f, gb = 0.f;
+#pragma unroll
+    for (int a = 0; a < AT; a++) { gw[a] = 0.f; wrow[a] = P[L.off.wq + jj * A + (a < A ? a : 0)]; }
+    float wvj = P[(L.dueling ? L.off.wv : L.off.bf1) + jj];
+    const float bias = P[L.off.bf1 + jj];
+    float hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int b = bg + 4 * u;
+        hv[u] = fc1_out(L.hf, L.stot, L.FC, b < B ? b : bg, jj, bias, L.nks);
+    }
+    const int tb = tid < B ? tid : 0;                            // threads past the batch recompute sample 0 and store nothing
+    const bool dbl = L.algo == FB_ALGO_DOUBLE;
+    float qsv[AT], qnv[AT], q3v[AT];
+#pragma unroll
+    for (int a = 0; a < AT; a++) {
+        const int ac = a < A ? a : 0;
+        qsv[a] = L.q[(size_t)tb * A + ac];
+        qnv[a] = L.q[(size_t)(B + tb) * A + ac];                 // DQN: online(s'); Nature/PER: target(s'); Double: online(s')
+        q3v[a] = L.q[(size_t)((dbl ? 2 * B : 0) + tb) * A + ac]; // Double only: target(s')
+    }
+    const float rf = L.rew[tb];
+    const int termb = L.term[tb], a_b = L.act[tb];
+    float isw = L.isw ? L.isw[tb] : 1.f;                         // (a kernel argument decides: uniform branch, taken by PER alone)
+#pragma unroll
+    for (int a = 0; a < AT; a++) { keep(wrow[a]); keep(qsv[a]); keep(qnv[a]); keep(q3v[a]); }
+    keep(wvj);
+#pragma unroll
+    for (int u = 0; u < 8; u++) keep(hv[u]);
+    if (!L.dueling) wvj = 0.f;
+    if (L.algo != FB_ALGO_PER) isw = 1.f;
+    // ---- targets
+    {
         float sel;
-        if (L.algo == FB_ALGO_DOUBLE) {                          // BrainDoubleDQN.py:51-54
+        if (dbl) {                                               // BrainDoubleDQN.py:51-54
             int am = 0;
-            for (int a = 1; a < A; a++) if (qn[a] > qn[am]) am = a;
-            sel = L.q[(size_t)(2 * B + tid) * A + am];
+#pragma unroll
+            for (int a = 1; a < AT; a++) if (a < A && qnv[a] > qnv[am]) am = a;
+            sel = q3v[0];
+#pragma unroll
+            for (int a = 1; a < AT; a++) sel = a == am ? q3v[a] : sel;
         } else {
-            sel = qn[0];
-            for (int a = 1; a < A; a++) sel = fmaxf(sel, qn[a]);
+            sel = qnv[0];
+#pragma unroll
+            for (int a = 1; a < AT; a++) sel = a < A ? fmaxf(sel, qnv[a]) : sel;
         }
         // BrainDQN.py:210-215: python float64 arithmetic on the rewards 0.1 / 3 / -3, then fed as float32
-        const float rf = L.rew[tid];
         const double r = rf == 0.1f ? 0.1 : (double)rf;
-        const double yd = L.term[tid] ? r : r + L.gamma * (double)sel;
+        const double yd = termb ? r : r + L.gamma * (double)sel;
         const float y = (float)yd;
-        const int a_b = L.act[tid];
-        const float d = y - qs[a_b];                             // q_eval = reduce_sum(Q * onehot)
-        const float w = L.algo == FB_ALGO_PER ? L.isw[tid] : 1.f;
-        lterm[tid] = w * d * d;
-        if (lead && L.abs_err) L.abs_err[tid] = fabsf(d);
-        if (lead && L.y_out) L.y_out[tid] = y;
+        float qe = qsv[0];
+#pragma unroll
+        for (int a = 1; a < AT; a++) qe = a == a_b ? qsv[a] : qe;
+        const float d = y - qe;                                  // q_eval = reduce_sum(Q * onehot)
+        const float w = isw;
         const float scale = L.algo == FB_ALGO_DQN ? 2.f : 2.f / (float)B;     // sum vs mean
         const float g = -scale * w * d;                          // dLoss/dQ[b][a_b]
-        if (L.dueling) {
-            dv[tid] = g;
-            for (int a = 0; a < A; a++) dadv[tid][a] = (a == a_b ? g : 0.f) - g / (float)A;
-        } else {
-            dv[tid] = 0.f;
-            for (int a = 0; a < A; a++) dadv[tid][a] = a == a_b ? g : 0.f;
+        if (tid < B) {
+            lterm[tid] = w * d * d;
+            if (lead && L.abs_err) L.abs_err[tid] = fabsf(d);
+            if (lead && L.y_out) L.y_out[tid] = y;
+            if (L.dueling) {
+                dv[tid] = g;
+#pragma unroll
+                for (int a = 0; a < AT; a++) dadv[tid][a] = (a == a_b ? g : 0.f) - g / (float)A;
+            } else {
+                dv[tid] = 0.f;
+#pragma unroll
+                for (int a = 0; a < AT; a++) dadv[tid][a] = a == a_b ? g : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -989,23 +1032,18 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     }
     if (lead && tid >= 64 && tid < 64 + A) { const int a = tid - 64; float s = 0.f; for (int b = 0; b < B; b++) s += dadv[b][a]; L.grad[L.off.bq + a] = s; }
     if (lead && tid == 128 && L.dueling) { float s = 0.f; for (int b = 0; b < B; b++) s += dv[b]; L.grad[L.off.bv] = s; }
-    const float *P = L.params;
-    const int jl = tid & 63, bg = tid >> 6, jj = blockIdx.x * 64 + jl;
-    float gw[MAXA], wrow[MAXA], gv = 0.f, gb = 0.f;
-#pragma unroll
-    for (int a = 0; a < MAXA; a++) { gw[a] = 0.f; wrow[a] = a < A ? P[L.off.wq + jj * A + a] : 0.f; }
-    const float wvj = L.dueling ? P[L.off.wv + jj] : 0.f, bias = P[L.off.bf1 + jj];
-    // 8 samples per round: their 8 x nks partial sums are requested together (one round trip per round instead of one
-    // per sample); the arithmetic and its order per sample are unchanged
+    // 8 samples per round: their 8 x nks partial sums are requested together (the first round's at the top of the kernel);
+    // the arithmetic and its order per sample are unchanged
     for (int b0 = bg; b0 < B; b0 += 32) {
-        float hv[8];
+        if (b0 != bg) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int b = b0 + 4 * u;
-            hv[u] = fc1_out(L.hf, L.stot, L.FC, b < B ? b : bg, jj, bias, L.nks);
+            for (int u = 0; u < 8; u++) {
+                const int b = b0 + 4 * u;
+                hv[u] = fc1_out(L.hf, L.stot, L.FC, b < B ? b : bg, jj, bias, L.nks);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) keep(hv[u]);
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) keep(hv[u]);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int b = b0 + 4 * u;
@@ -1013,7 +1051,7 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
                 const float h = hv[u];
                 float d = dv[b] * wvj;
 #pragma unroll
-                for (int a = 0; a < MAXA; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
+                for (int a = 0; a < AT; a++) if (a < A) { d = fmaf(dadv[b][a], wrow[a], d); gw[a] = fmaf(h, dadv[b][a], gw[a]); }
                 gv = fmaf(h, dv[b], gv);
                 const float dh = h > 0.f ? d : 0.f;
                 L.dhf[(size_t)b * L.FC + jj] = dh;
@@ -1022,16 +1060,25 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
         }
     }
 #pragma unroll
-    for (int a = 0; a < MAXA; a++) part[bg][jl][a] = gw[a];
+    for (int a = 0; a < AT; a++) part[bg][jl][a] = gw[a];
     part[bg][jl][MAXA] = gv; part[bg][jl][MAXA + 1] = gb;
     __syncthreads();
     if (bg == 0) {
 #pragma unroll
-        for (int a = 0; a < MAXA; a++)
+        for (int a = 0; a < AT; a++)
             if (a < A) L.grad[L.off.wq + jj * A + a] = ((part[0][jl][a] + part[1][jl][a]) + part[2][jl][a]) + part[3][jl][a];
         if (L.dueling) L.grad[L.off.wv + jj] = ((part[0][jl][MAXA] + part[1][jl][MAXA]) + part[2][jl][MAXA]) + part[3][jl][MAXA];
         L.grad[L.off.bf1 + jj] = ((part[0][jl][MAXA + 1] + part[1][jl][MAXA + 1]) + part[2][jl][MAXA + 1]) + part[3][jl][MAXA + 1];
     }
+}
+
+__global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
+    __shared__ float dadv[MAXTB][MAXA];
+    __shared__ float dv[MAXTB];
+    __shared__ float lterm[MAXTB];
+    __shared__ float part[4][64][MAXA + 2];
+    if (L.A == 2) loss_head_body<2>(L, dadv, dv, lterm, part);
+    else loss_head_body<MAXA>(L, dadv, dv, lterm, part);
 }
 
 __global__ void adam_tick_kernel(AdamDev *ad) {
