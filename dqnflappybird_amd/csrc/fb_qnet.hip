@@ -1159,7 +1159,7 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
         // every load of the chunk is issued unconditionally from a clamped (valid) address -- 48 loads in flight instead
         // of 48 dependent round trips -- pinned (keep), and only then masked by selects
         float a[16], bb[16], dv[16], xv[16];
-        int am[16];
+        int am[16], xr[16];
         bool mok[16], in[16];
         int par[16];
         // position c0 of the chunk is wave-uniform: its (sample, oy, ox) come from scalar divisions once; the 32 positions
@@ -1184,17 +1184,24 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
                 par[t] = (oy & 1) * 2 + (ox & 1);
                 const int ix = ox * 4 - 2 + (i >> 2);
                 in[t] = iy >= 0 && iy < 80 && ix >= 0 && ix < 80;
-                xv[t] = (float)xu8[(((uint32_t)b * 80u + (uint32_t)(in[t] ? iy : 0)) * 80u + (uint32_t)(in[t] ? ix : 0)) * 4u + (uint32_t)(i & 3)];
+                xr[t] = xu8[(((uint32_t)b * 80u + (uint32_t)(in[t] ? iy : 0)) * 80u + (uint32_t)(in[t] ? ix : 0)) * 4u + (uint32_t)(i & 3)];
             } else {
-                am[t] = 0; par[t] = 0;
+                am[t] = 0; par[t] = 0; xr[t] = 0;
                 dv[t] = dy[(uint32_t)m * (uint32_t)G::CO + (uint32_t)(cot * 32 + j)];
                 const int ix = ox * G::S + kx - G::P;
                 in[t] = iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
                 xv[t] = x[(((uint32_t)b * G::IH + (uint32_t)(in[t] ? iy : 0)) * G::IW + (uint32_t)(in[t] ? ix : 0)) * G::CI + (uint32_t)(cit * 32 + i)];
             }
         }
+        // the pins take the RAW loaded values (a conversion between a load and its pin drags the load down to the pin: the
+        // byte loads of conv1 then went out two at a time, each pair behind a vmcnt(0)), behind a scheduling fence
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 16; t++) { keep(dv[t]); keep(xv[t]); if (LAYER == 1) keep(am[t]); }
+        for (int t = 0; t < 16; t++) { keep(dv[t]); if (LAYER == 1) { keep(xr[t]); keep(am[t]); } else keep(xv[t]); }
+        if (LAYER == 1) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) xv[t] = (float)xr[t];
+        }
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             bb[t] = mok[t] && am[t] == par[t] ? dv[t] : 0.f;                         // max_pool routes to the arg max
