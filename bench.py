@@ -244,7 +244,8 @@ def main():
         for k, name, flop, split in act:
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
                                                                   None, None, st()), "profile"), R)
-            add(name + "[act n=1024]", us, 1, "mfma", flop * N_ENVS, split)
+            # (inside fb_vec_step the head does not get a launch of its own: it rides in the env step launch)
+            add(name + "[act n=1024]", us, 0 if name == "head_kernel" else 1, "mfma", flop * N_ENVS, split)
         # train step, B = 32 (forward kernels see 2B samples: s and s')
         scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
         for k in range(64):

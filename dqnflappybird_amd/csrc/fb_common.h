@@ -76,6 +76,7 @@ struct FbPushRider { unsigned long long *bits; uint8_t *act; float *rew; uint8_t
 // library-internal (C++ linkage): the env step with the replay sampler as an extra workgroup, and the replay side of it
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream);
+int fb_qnet_num_actions(fb_qnet_t h);
 int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,

@@ -58,7 +58,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // every env has a workgroup of its own there
     FbHeadRider hrider;
     static const bool head_rides = !(getenv("FB_VEC_HEAD_RIDER") && atoi(getenv("FB_VEC_HEAD_RIDER")) == 0);      // tuning knob
-    const int have_h = head_rides && fb_env_can_carry_head(env);
+    const int have_h = head_rides && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2;
     int rc = have_h ? fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, stream)
                     : fb_qnet_act_nib(net, b->nib, n_envs, epsilon, seed, step, b->actions, nullptr, stream);
     if (rc != FB_OK) return rc;

@@ -131,7 +131,7 @@ __device__ __forceinline__ int nib_word(int w) { return (w / 10 + 2) * (FB_NIB_P
 
 // ------------------------------------------------------------------ the step kernel
 template <bool STEP>
-__global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
+__global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const uint8_t *__restrict__ actions,
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ frame_bits,
                                                   float *__restrict__ reward, uint8_t *__restrict__ terminal,
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_kernel(EnvParams p, const uin
         // fb_vec_step: the acting path's head rides here -- wave 0 turns this env's fc1 partial sums into its Q values and
         // its epsilon-greedy action (head_one: head_kernel's own code) while the tables above are on their way
         if (STEP && head.on && threadIdx.x < 64) {
-            const int a = head_one(head.c, head.params, env, threadIdx.x);
+            const int a = head_one_t<2>(head.c, head.params, env, threadIdx.x);      // the game has two actions (the host checks)
             if (threadIdx.x == 0) act_mail = a;             // handed to the other waves through LDS
         }
     }
@@ -616,7 +616,7 @@ int fb_env_can_carry_head(fb_env_t h) { return h && h->grid == h->p.n_envs; }
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
-    FB_REQUIRE(!head || h->grid == h->p.n_envs, "fb_env_step: the head rider needs one workgroup per env");
+    FB_REQUIRE(!head || (h->grid == h->p.n_envs && head->c.A == 2), "fb_env_step: the head rider needs one workgroup per env and a 2-action net");
     FbSampleRider r;
     FbPushRider q;
     FbHeadRider hd;

@@ -1760,6 +1760,8 @@ extern "C" int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, fl
     return FB_OK;
 }
 
+int fb_qnet_num_actions(fb_qnet_t h) { return h ? h->A : 0; }
+
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                           uint8_t *actions, FbHeadRider *head, void *stream) {
     FB_REQUIRE(h && nib_states && actions && head, "fb_qnet_act_nib_rider: NULL argument");

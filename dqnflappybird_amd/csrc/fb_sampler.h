@@ -28,6 +28,13 @@ __device__ __forceinline__ void mt_regen(uint32_t *mt, int lane) {
     }
 }
 
+// result i lives in register slot i >> 6 of lane i & 63; written with compile-time slot indices (a run-time index into the
+// register array would put it in scratch memory -- and a kernel that touches scratch pays for it at every launch)
+__device__ __forceinline__ void set_sel(long long (&sel)[4], int i, int lane, long long v) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q == (i >> 6) && lane == (i & 63)) sel[q] = v;
+}
+
 // random.sample(range(n), k) on one wave.  Set path (n > setsize, the normal case): the wave tempers up to
 // 64 state words at once, ballots the ones below n and walks only those, in stream order, testing each
 // against the already selected values with one wave-wide compare -- no per-word LDS round trip.  Words are
@@ -90,7 +97,7 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
 #pragma unroll
                 for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
                 if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
-                if (lane == (i & 63)) sel[i >> 6] = c;
+                set_sel(sel, i, lane, c);
                 if (++i == k) { consumed = l + 1; break; }
             }
             idx += consumed;
@@ -110,7 +117,7 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) pool[r] = pool[m - 1];
             __builtin_amdgcn_wave_barrier();
-            if (lane == (i & 63)) sel[i >> 6] = res;
+            set_sel(sel, i, lane, res);
         }
     }
 #pragma unroll

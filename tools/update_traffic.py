@@ -1,7 +1,7 @@
 """profiles/traffic.json (HBM bytes per launch, keyed by bench.py's kernel labels) from the two rocprofv3 --pmc passes of
 tools/pmc_passes.sh: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE reads half on gfx950)."""
 import collections, csv, glob, json, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01h"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01i"
 
 
 def mean_counter(dirpat, cname):
@@ -14,7 +14,7 @@ def mean_counter(dirpat, cname):
 
 
 fe, wr = mean_counter(f"gpurun_out/{tag}_pmc_fetch", "FETCH_SIZE"), mean_counter(f"gpurun_out/{tag}_pmc_write", "WRITE_SIZE")
-json.dump({k: {"FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0)} for k in fe}, open("profiles/r01_h_pmc_fetch_write_raw.json", "w"), indent=1)
+json.dump({k: {"FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0)} for k in fe}, open("profiles/r01_i_pmc_fetch_write_raw.json", "w"), indent=1)
 t = json.load(open("profiles/traffic.json"))
 labels = {"conv1_sp_kernel<nib>[act n=1024]": "conv1_sp_kernel<true>", "conv23_sp_kernel[act n=1024]": "conv23_sp_kernel<3>",
           "fc1_sp_kernel[act n=1024]": "fc1_sp_kernel<3>", "head_kernel[act n=1024]": "head_kernel", "env_kernel<true>[n=1024]": "env_kernel<true>",
