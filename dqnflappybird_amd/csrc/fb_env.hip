@@ -374,7 +374,7 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
                 for (int m = 0; m < 8; m++) top |= ((t >> m) & 1u) << (4 * m + 3);
                 uint32_t old = 0u;
                 const int pw = nib_word(w);
-                if (STEP) old = first ? nib0[w >= ENV_THREADS ? 1 : 0] : dst[pw];
+                if (STEP) old = first ? (w >= ENV_THREADS ? nib0[1] : nib0[0]) : dst[pw];     // (no run-time register index: scratch)
                 dst[pw] = STEP ? (((old >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
             }
         }
