@@ -11,7 +11,7 @@ timeStep % 500 == 0, PER never does.
 import torch
 
 from . import dist as fdist
-from .vec import QNet, VecGameState, VecReplay
+from .vec import QNet, VecGameState, VecReplay, VecStep
 
 MEAN_LOSS = {"dqn": False, "nature": True, "double": True, "per": True}
 
@@ -40,6 +40,9 @@ class VecBrain:
         self.replay.reset(self.env.frame_bits)
         self.stats = self.env.track_stats()                  # [episodes, score sum, score max, pipes passed], kept by the env kernel
         self.last_loss = None
+        # uniform replay: the whole step is one host call (fb_vec_step), with the head, random.sample and the Memory append
+        # riding in the env launch; PER keeps the separate calls (its sample returns the importance weights)
+        self.one_step = VecStep(self.env, self.replay, self.net, batch, algo, gamma, flat_grad=self.grad) if algo != "per" else None
 
     def train_step(self, idx=None):
         if self.algo in ("nature", "double") and self.timeStep % self.replace_target_iter == 0:
@@ -58,6 +61,21 @@ class VecBrain:
         self.last_loss = loss
 
     def step(self):
+        if self.one_step is not None:
+            training = self.onlineTimeStep > self.observe
+            if training and self.algo in ("nature", "double") and self.timeStep % self.replace_target_iter == 0:
+                self.net.sync_target()                       # acting reads the online net only: same result as syncing before training
+            self.one_step(self.epsilon, seed=self.seed + self.rank, step=self.timeStep, train=training)
+            if self.epsilon > self.final_epsilon and self.onlineTimeStep > self.observe:
+                self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
+            if training:
+                if self.grad is not None:
+                    fdist.allreduce_gradients(self.grad, MEAN_LOSS[self.algo])
+                    self.net.apply_adam(self.grad)
+                self.last_loss = self.one_step.loss
+            self.timeStep += 1
+            self.onlineTimeStep += 1
+            return
         actions = self.net.act_nib(self.nib, self.epsilon, seed=self.seed + self.rank, step=self.timeStep)
         if self.epsilon > self.final_epsilon and self.onlineTimeStep > self.observe:
             self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
