@@ -253,8 +253,11 @@ const char *fb_qnet_kernel_name(int kernel);
 /* ------------------------------------------------------------------ one whole step of the vectorised loop
  * FlappyBirdDQN.py:72-76 for N envs in ONE call (uniform replay): getAction (fb_qnet_act_nib) -> frame_step
  * (fb_env_step, packed frames) -> store + random.sample (fb_replay_push_sample) -> minibatch (fb_replay_gather)
- * -> _trainQNetwork (fb_qnet_train_step).  Exactly those calls in that order on `stream`; what it saves is the
- * host's per-call overhead between launches (the GPU otherwise idles ~15 us per step waiting for the interpreter).
+ * -> _trainQNetwork (fb_qnet_train_step).  The results of exactly those calls in that order on `stream`.  It saves the
+ * host's per-call overhead between launches (the GPU otherwise idles ~15 us per step waiting for the interpreter) and
+ * four launches: the head of the acting forward (fc2 + epsilon-greedy action), random.sample and the Memory append
+ * ride inside the env step launch (uniform memory, CPython generator, <= 2048 envs and 2 actions for the head; anything
+ * else keeps its own launch), bit-identical to the separate calls.
  * All pointers [dev], caller owned; nib is the buffer given to fb_env_set_nib_buffer.  train = 0 stops after the
  * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
  * fb_qnet_apply_adam). */
