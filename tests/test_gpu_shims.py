@@ -186,12 +186,15 @@ def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cu
         rep.push(env.frame_bits, acts, env.reward, env.terminal)
 
 
-def test_vec_step_single_call_equals_separate_calls(torch_cuda):
-    """fb_vec_step (one host call per step) == act_nib -> frame_step -> push_sample -> gather -> train_step:
-    same actions, env states, sampled indices and parameters after 40 steps (8 of them in the OBSERVE phase)."""
+@pytest.mark.parametrize("N,steps", [(256, 40), (2304, 24)])
+def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
+    """fb_vec_step (one host call per step; head, random.sample and the Memory append riding in the env launch) ==
+    act_nib -> frame_step -> push_sample -> gather -> train_step: same actions, env states, sampled indices and
+    parameters after `steps` steps (8 of them in the OBSERVE phase).  2304 envs: more envs than env workgroups (the
+    head keeps its own launch, the env kernel strides) and a ring that wraps."""
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
-    N, B = 256, 32
+    B = 32
 
     def make():
         env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
@@ -202,7 +205,7 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda):
     e1, r1, n1, nib1 = make()
     e2, r2, n2, nib2 = make()
     one = VecStep(e2, r2, n2, B, "dqn")
-    for step in range(40):
+    for step in range(steps):
         train = step >= 8
         a1 = n1.act_nib(nib1, 0.05, seed=1, step=step)
         e1.frame_step(a1, want_u8=False)
@@ -219,6 +222,11 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda):
     assert (e1.get_state() == e2.get_state()).all()
     assert torch.equal(n1.store_params(), n2.store_params())
     assert torch.equal(nib1, nib2)
+    # the ring the riders filled holds what the push kernel stores: oldest, newest and a stride of positions in between
+    assert len(r1) == len(r2)
+    probe = torch.cat([torch.arange(0, 48), torch.arange(100, len(r1) - 48, 331), torch.arange(len(r1) - 48, len(r1))]).cuda()
+    for x, y in zip(r1.gather(probe), r2.gather(probe)):
+        assert torch.equal(x, y)
 
 
 def test_standalone_dueling_recipe_on_device(torch_cuda, tmp_path, monkeypatch):
