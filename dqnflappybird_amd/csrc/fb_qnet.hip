@@ -498,12 +498,18 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
                                                                   size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int resplit) {
     __shared__ uint4 wl[3 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    // this workgroup's weight copy goes out first, the re-split items' loads right behind it (one round trip, not two)
+    constexpr int WQ = 3 * 16 * 64, WC = (WQ + 64 * C1_WAVES - 1) / (64 * C1_WAVES);
+    uint4 wcopy[WC];
+#pragma unroll
+    for (int u = 0; u < WC; u++) { const int q = threadIdx.x + u * 64 * C1_WAVES; wcopy[u] = reinterpret_cast<const uint4 *>(s.w1s)[q < WQ ? q : 0]; }
     if (resplit) {
         const int items = 64 * 64 + 72 * 64 + 200 * FC;
         for (int id = blockIdx.x * (64 * C1_WAVES) + threadIdx.x; id < items; id += gridDim.x * (64 * C1_WAVES)) wsplit_item(s.params, wsp, FC, id);
     }
-    const int bid = blockIdx.x, nblk = gridDim.x;
-    for (int q = threadIdx.x; q < 3 * 16 * 64; q += 64 * C1_WAVES) wl[q] = reinterpret_cast<const uint4 *>(s.w1s)[q];
+#pragma unroll
+    for (int u = 0; u < WC; u++) { const int q = threadIdx.x + u * 64 * C1_WAVES; if (q < WQ) wl[q] = wcopy[u]; }
     if (NIB && threadIdx.x < 256) {
         const unsigned t = threadIdx.x;
         uint4 e;
