@@ -53,7 +53,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dqnflappybird_amd import _lib as L
-    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    from dqnflappybird_amd.vec import QNet, TrainSteps, VecGameState, VecReplay, VecStep
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,13 +165,13 @@ def main():
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            train10 = TrainSteps(replay, net, BATCH, "dqn")
             with torch.cuda.stream(side):
-                train(0)
+                train10(1)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
-                for _ in range(10):
-                    train(0)
+                train10(10)                                  # fb_train_steps: 10 x (sample -> gather -> train), one host call
             g.replay()
             torch.cuda.synchronize()
             graph_used = True
@@ -353,7 +353,7 @@ def main():
             "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",
                        "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
                        "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
-                       "train_leg": "hipGraph x10" if graph_used else "eager",
+                       "train_leg": "fb_train_steps(10) in one hipGraph" if graph_used else "eager",
                        "parallelism": f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat "
                                       f"gradient per step" if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

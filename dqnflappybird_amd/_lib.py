@@ -70,6 +70,7 @@ SIGNATURES = {
     "fb_qnet_act_nib": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],
     "fb_qnet_train_step": [_vp, _i, _i] + [_vp] * 6 + [_d] + [_vp] * 5,
     "fb_qnet_apply_adam": [_vp, _vp, _vp],
+    "fb_train_steps": [_vp, _vp, _i, _i, _i] + [_vp] * 7 + [_d, _vp],
     "fb_qnet_sync_target": [_vp, _vp],
     "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
     "fb_qnet_kernel_name": [_i],

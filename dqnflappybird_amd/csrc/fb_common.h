@@ -84,8 +84,11 @@ int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float e
 // the rider for "fb_replay_push" of a uniform memory (returns 1, fills *push and COUNTS the push: the env launch that
 // carries it must follow), 0 for a prioritized memory (its tree update needs its own launches)
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push);
-// the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after ONE more push).  Returns 1 and
+// the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after `pushes_ahead` more pushes).  Returns 1 and
 // fills *rider for a uniform memory with the CPython generator, 0 when the sampler cannot ride (PER, other generators).
-int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider);
+int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider, int pushes_ahead = 1);
+// fb_qnet_train_step (fused Adam) with a random.sample rider in its conv3 backward launch (rider may be NULL)
+int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int batch, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
+                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, void *stream);
 void fb_mt_init_genrand_host(FbMT *s, uint32_t seed);
 void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int n);

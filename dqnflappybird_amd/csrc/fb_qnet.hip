@@ -27,6 +27,7 @@ constexpr int OFF_W1 = 0, OFF_B1 = 8192, OFF_W2 = 8224, OFF_B2 = 40992, OFF_W3 =
               OFF_WF1 = 77984;
 constexpr int CONV_PARAMS = OFF_WF1;         // everything in front of W_fc1
 #include "fb_head.h"               // MAXA, FC1_KS, sel4, head_one
+#include "fb_sampler.h"            // the replay sampler can ride in the conv3 backward launch (fb_train_steps)
 constexpr int MAXTB = 256;
 
 
@@ -1306,13 +1307,22 @@ __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan
 __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh3, const float *__restrict__ h2,
                                                         float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B,
-                                                        int n_adam, AdamSpan span) {
+                                                        int n_adam, AdamSpan span, FbSampleRider rider) {
     __shared__ float red[9 * 16 * 64];
-    const int n_conv = gridDim.x - n_adam;
-    if ((int)blockIdx.x >= n_conv) adam_span_body(blockIdx.x - n_conv, n_adam, span);
-    else if ((int)blockIdx.x < n_dx) conv3_dx_body(blockIdx.x, red, params, dh3, h2, dh2, B);
+    static_assert(sizeof(red) >= FB_SAMPLE_LDS_WORDS * 4, "the sampler borrows the reduction buffer");
+    // fb_train_steps: random.sample for the NEXT train step rides as workgroup 0 (one wave of it): it needs the generator
+    // and the memory's size only, and this launch is the longest of the step
+    const int rid = rider.k ? 1 : 0, bid = (int)blockIdx.x - rid;
+    if (bid < 0) {
+        uint32_t *words = reinterpret_cast<uint32_t *>(red);
+        if (threadIdx.x < 64) sample_cpython_body(rider.ctx, rider.k, rider.setsize, rider.out, words, reinterpret_cast<int *>(words + 624));
+        return;
+    }
+    const int n_conv = (int)gridDim.x - rid - n_adam;
+    if (bid >= n_conv) adam_span_body(bid - n_conv, n_adam, span);
+    else if (bid < n_dx) conv3_dx_body(bid, red, params, dh3, h2, dh2, B);
     else {
-        const int t = blockIdx.x - n_dx;
+        const int t = bid - n_dx;
         conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride);
     }
 }
@@ -1602,6 +1612,7 @@ struct Plan {
     int algo, B; const uint8_t *s, *a, *t; const float *r, *isw; double gamma;
     float *loss, *abs_err, *y, *G; bool apply_adam, tick;
     FbHeadRider *head_rider;                 // acting path: describe the head work instead of launching it (fb_vec_step)
+    const FbSampleRider *sample_rider;       // train plan: random.sample for the next step rides in the conv3 backward launch
 };
 
 static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
@@ -1699,8 +1710,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
         const int n_adam = (span1 - span0 + 575) / 576;
         const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
-        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam), dim3(576), 0, st, ndx3, z3, h->params[0], h->dh3, h->h2,
-                                             h->dh2, h->slabs, ss, B, n_adam, span);
+        FbSampleRider srider;
+        memset(&srider, 0, sizeof(srider));
+        if (p.sample_rider) srider = *p.sample_rider;
+        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam + (srider.k ? 1 : 0)), dim3(576), 0, st, ndx3, z3,
+                                             h->params[0], h->dh3, h->h2, h->dh2, h->slabs, ss, B, n_adam, span, srider);
         const int ndx2 = ((B * 25 + 31) / 32) * 4;
         FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
                                              h->dp1, h->slabs, ss, B);
@@ -1819,6 +1833,15 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
     p.apply_adam = flat_grad == nullptr; p.tick = true;
     *out = p;
     return FB_OK;
+}
+
+int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
+                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, void *stream) {
+    Plan p;
+    int rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, gamma, loss, nullptr, nullptr, nullptr, &p);
+    if (rc != FB_OK) return rc;
+    p.sample_rider = rider;
+    return run_plan(h, p, -1, fb_stream(stream));
 }
 
 extern "C" int fb_qnet_train_step(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r,

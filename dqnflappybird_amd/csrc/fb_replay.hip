@@ -671,10 +671,10 @@ int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
     return 1;
 }
 
-int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider) {
+int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider, int pushes_ahead) {
     const ReplayParams &P = h->P;
     if (P.kind != FB_REPLAY_UNIFORM || P.rng_kind != FB_RNG_CPYTHON || batch < 1 || batch > MAXB || !idx) return 0;
-    const long long total = (h->host_steps + 1) * P.n_envs;
+    const long long total = (h->host_steps + pushes_ahead) * P.n_envs;
     rider->ctx = FbSampleCtx{P.mt, &P.dev->error, total < P.cap ? total : P.cap};
     rider->k = batch; rider->setsize = cpython_setsize(batch); rider->out = (long long *)idx;
     return 1;

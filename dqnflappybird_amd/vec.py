@@ -351,6 +351,30 @@ class QNet:
         L.check(L.lib().fb_qnet_apply_adam(self.h, L.ptr(flat_grad), L.current_stream()), "fb_qnet_apply_adam")
 
 
+class TrainSteps:
+    """n x (random.sample -> minibatch -> _trainQNetwork) on a uniform memory that is not being pushed to, as one host call
+    (fb_train_steps): the separate calls' results, with the next step's random.sample riding in the conv3 backward launch."""
+
+    def __init__(self, replay, net, batch=32, algo="dqn", gamma=0.99):
+        if replay.prioritized or algo == "per":
+            raise ValueError("TrainSteps is for uniform replay (PER needs the importance weights: use the separate calls)")
+        self.replay, self.net, self.batch, self.algo, self.gamma = replay, net, batch, ALGOS[algo], float(gamma)
+        dev, B = replay.device, batch
+        self.idx = torch.zeros(2 * B, dtype=torch.int64, device=dev)     # two buffers, used alternately
+        self.s = torch.empty((B, 80, 80, 4), dtype=torch.uint8, device=dev)
+        self.s2 = torch.empty((B, 80, 80, 4), dtype=torch.uint8, device=dev)
+        self.a = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.r = torch.empty(B, dtype=torch.float32, device=dev)
+        self.t = torch.empty(B, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def __call__(self, n_steps=1):
+        L.check(L.lib().fb_train_steps(self.replay.h, self.net.h, self.algo, self.batch, int(n_steps), L.ptr(self.idx), L.ptr(self.s),
+                                       L.ptr(self.s2), L.ptr(self.a), L.ptr(self.r), L.ptr(self.t), L.ptr(self.loss), self.gamma,
+                                       L.current_stream()), "fb_train_steps")
+        return self.loss
+
+
 class VecStep:
     """One whole step of the vectorised loop (FlappyBirdDQN.py:72-76 for N envs, uniform replay) as a single
     host call, fb_vec_step: getAction -> frame_step -> store + random.sample -> minibatch -> _trainQNetwork.

@@ -250,3 +250,43 @@ def test_standalone_dueling_recipe_on_device(torch_cuda, tmp_path, monkeypatch):
     assert np.array_equal(z["target"], t0) and not np.array_equal(net.get_params(1), t0)
     q = net.q_values(obs)
     assert q.shape == (2,) and np.isfinite(q).all()
+
+
+def test_train_steps_single_call_equals_separate_calls(torch_cuda):
+    """fb_train_steps (n x sample -> gather -> train in one call, the next step's random.sample riding in the conv3 backward
+    launch) == the separate calls: same index stream, same parameters."""
+    torch = torch_cuda
+    from dqnflappybird_amd import _lib as L
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+    N, B = 256, 32
+
+    def make():
+        env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+        rep.seed(9, "cpython"); net.init_params(3)
+        env.observe(); rep.reset(env.frame_bits)
+        acts = (torch.rand(N, generator=torch.Generator().manual_seed(1)) < 0.1).to(torch.uint8).cuda()
+        for _ in range(12):
+            env.frame_step(acts, want_u8=False)
+            rep.push(env.frame_bits, acts, env.reward, env.terminal)
+        return rep, net
+
+    r1, n1 = make()
+    r2, n2 = make()
+    seen = []
+    for _ in range(7):
+        idx, _ = r1.sample(B)
+        seen.append(idx.clone())
+        s, a, r, s2, t = r1.gather(idx)
+        n1.train_step("dqn", s, a, r, s2, t, want_aux=False)
+    idx2 = torch.zeros(2 * B, dtype=torch.int64, device="cuda")
+    s, a, r, s2, t = r2.gather(idx2[:B].contiguous())                    # buffers of the right shapes
+    loss = torch.zeros(1, device="cuda")
+    for n in (3, 4):                                                     # two calls: the stream continues across them
+        L.check(L.lib().fb_train_steps(r2.h, n2.h, 0, B, n, L.ptr(idx2), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r), L.ptr(t), L.ptr(loss),
+                                       0.99, L.current_stream()), "fb_train_steps")
+        last = n - 1
+        want = seen[2] if n == 3 else seen[6]
+        assert torch.equal(idx2[(last & 1) * B:(last & 1) * B + B], want)
+    assert torch.equal(n1.store_params(), n2.store_params())
+    nxt1, _ = r1.sample(B); nxt2, _ = r2.sample(B)                       # and the generators are in the same place
+    assert torch.equal(nxt1, nxt2)
