@@ -69,6 +69,14 @@ struct HeadCore {
     uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
 };
 struct FbHeadRider { HeadCore c; const float *params; int on; };
+// fb_replay_gather as a rider of another module's launch (fb_gather.h; B == 0: no rider): what the kernel needs of the ring
+struct FbGatherCtx {
+    long long cap; int n_envs, t_f, kind;
+    const unsigned long long *bits; const uint8_t *act; const float *rew; const uint8_t *term; int *error;
+};
+struct FbGatherRider { FbGatherCtx c; long long steps; int B; const long long *idx; uint8_t *s, *s2, *a; float *r; uint8_t *t; };
+int fb_replay_gather_rider(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r, uint8_t *t,
+                           FbGatherRider *rider);
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
 // into the ring slot of the coming push (bits: slot of env 0's frame, +100 words per env; act / rew / term: row of the
 // step, +1 per env; bits == NULL: no rider).  steps_dev receives steps_new (the device mirror of the push counter).
@@ -87,8 +95,10 @@ int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push);
 // the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after `pushes_ahead` more pushes).  Returns 1 and
 // fills *rider for a uniform memory with the CPython generator, 0 when the sampler cannot ride (PER, other generators).
 int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider, int pushes_ahead = 1);
-// fb_qnet_train_step (fused Adam) with a random.sample rider in its conv3 backward launch (rider may be NULL)
+// fb_qnet_train_step (fused Adam) with a random.sample rider in its conv3 backward launch and the NEXT step's gather in its
+// Adam launch (either may be NULL)
 int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int batch, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
-                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, void *stream);
+                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, const FbGatherRider *gather,
+                             void *stream);
 void fb_mt_init_genrand_host(FbMT *s, uint32_t seed);
 void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int n);

@@ -49,21 +49,27 @@ void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int key_length) {
 }
 
 // n x (random.sample -> minibatch -> _trainQNetwork) on a memory that is not being pushed to, as one host call.  Only the
-// first draw gets a launch of its own: the draw for step i + 1 rides in step i's conv3 backward launch (it needs the
-// generator and len(memory), nothing of step i), so the ~6 us single-wave sampler leaves the chain of dependent launches.
+// first draw and the first gather get launches of their own: the draw for step i + 1 rides in step i's conv3 backward launch
+// (it needs the generator and len(memory), nothing of step i) and the gather of step i + 1 in step i's Adam launch (nothing of
+// step i reads the minibatch buffers by then): sampler and gather leave the chain of dependent launches.
 // idx holds two index buffers used alternately; the indices of step i end up in idx[(i & 1) * batch ..).
 extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int batch, int n_steps, int64_t *idx, uint8_t *s,
                               uint8_t *s2, uint8_t *a, float *r, uint8_t *t, float *loss, double gamma, void *stream) {
     FB_REQUIRE(replay && net && idx && s && s2 && a && r && t && loss && n_steps >= 1, "fb_train_steps: bad argument");
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_train_steps: prioritized replay needs the importance weights: use the separate calls");
     int rc = fb_replay_sample(replay, batch, nullptr, idx, nullptr, stream);
+    bool gathered = false;                               // the minibatch of step i is already in s / s2 / a / r / t
     for (int i = 0; rc == FB_OK && i < n_steps; i++) {
         int64_t *cur = idx + (size_t)(i & 1) * batch, *nxt = idx + (size_t)((i + 1) & 1) * batch;
-        rc = fb_replay_gather(replay, batch, cur, s, s2, a, r, t, stream);
+        if (!gathered) rc = fb_replay_gather(replay, batch, cur, s, s2, a, r, t, stream);
         if (rc != FB_OK) break;
-        FbSampleRider rider;
-        const int rides = i + 1 < n_steps && fb_replay_sample_rider(replay, batch, nxt, &rider, 0);
-        rc = fb_qnet_train_step_rider(net, algo, batch, s, a, r, s2, t, gamma, loss, rides ? &rider : nullptr, stream);
+        FbSampleRider srider;
+        FbGatherRider grider;
+        const int rides = i + 1 < n_steps && fb_replay_sample_rider(replay, batch, nxt, &srider, 0) &&
+                          fb_replay_gather_rider(replay, batch, nxt, s, s2, a, r, t, &grider);
+        rc = fb_qnet_train_step_rider(net, algo, batch, s, a, r, s2, t, gamma, loss, rides ? &srider : nullptr,
+                                      rides ? &grider : nullptr, stream);
+        gathered = rides;
         if (rc == FB_OK && i + 1 < n_steps && !rides) rc = fb_replay_sample(replay, batch, nullptr, nxt, nullptr, stream);
     }
     return rc;

@@ -28,6 +28,7 @@ constexpr int OFF_W1 = 0, OFF_B1 = 8192, OFF_W2 = 8224, OFF_B2 = 40992, OFF_W3 =
 constexpr int CONV_PARAMS = OFF_WF1;         // everything in front of W_fc1
 #include "fb_head.h"               // MAXA, FC1_KS, sel4, head_one
 #include "fb_sampler.h"            // the replay sampler can ride in the conv3 backward launch (fb_train_steps)
+#include "fb_gather.h"             // ... and the next step's minibatch gather in the Adam launch
 constexpr int MAXTB = 256;
 
 
@@ -1379,10 +1380,18 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
                                                    const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad,
                                                    const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
-                                                   uint16_t *__restrict__ w1s, int skip0, int skip1) {
+                                                   uint16_t *__restrict__ w1s, int skip0, int skip1, int n_adam_blocks,
+                                                   FbGatherRider gr) {
+    // fb_train_steps: the NEXT step's minibatch gather rides behind the Adam blocks (its indices were drawn in the conv3
+    // backward launch; nothing of this step reads the minibatch buffers any more)
+    if ((int)blockIdx.x >= n_adam_blocks) {
+        gather_body<false>(gr.c, gr.steps, gr.B, gr.idx, (uint4 *)gr.s, (uint4 *)gr.s2, gr.a, gr.r, gr.t,
+                           (long long)((int)blockIdx.x - n_adam_blocks) * 256 + threadIdx.x);
+        return;
+    }
     const float alpha = ad->alpha, omb1 = 1.f - ad->b1, omb2 = 1.f - ad->b2, eps = ad->eps;
     const long long n4 = n >> 2, nq = n4 - (skip1 - skip0);      // float4s [skip0, skip1) were updated by an AdamSpan already
-    for (long long qq = (long long)blockIdx.x * 256 + threadIdx.x; qq < nq; qq += (long long)gridDim.x * 256) {
+    for (long long qq = (long long)blockIdx.x * 256 + threadIdx.x; qq < nq; qq += (long long)n_adam_blocks * 256) {
         const long long q = qq < skip0 ? qq : qq + (skip1 - skip0);
         float4 P = reinterpret_cast<float4 *>(p)[q], Mv = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
         float4 Gv;
@@ -1613,6 +1622,7 @@ struct Plan {
     float *loss, *abs_err, *y, *G; bool apply_adam, tick;
     FbHeadRider *head_rider;                 // acting path: describe the head work instead of launching it (fb_vec_step)
     const FbSampleRider *sample_rider;       // train plan: random.sample for the next step rides in the conv3 backward launch
+    const FbGatherRider *gather_rider;       // ... and its minibatch gather in the Adam launch
 };
 
 static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
@@ -1730,8 +1740,14 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
-            hipLaunchKernelGGL(adam_kernel, dim3((int)((h->n / 4 - (span1 - span0) + 255) / 256)), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G,
-                               h->n, h->adam, (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0], span0, span1);
+        {
+            FbGatherRider gr;
+            memset(&gr, 0, sizeof(gr));
+            if (p.gather_rider) gr = *p.gather_rider;
+            const int nab = (int)((h->n / 4 - (span1 - span0) + 255) / 256), ngb = (int)(((long long)gr.B * 1600 + 255) / 256);
+            hipLaunchKernelGGL(adam_kernel, dim3(nab + ngb), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G,
+                               h->n, h->adam, (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0], span0, span1, nab, gr);
+        }
         if (p.apply_adam && (only < 0 || only == K_ADAM)) h->wsp_stale[0] = true;
     }
 #undef FB_K
@@ -1799,7 +1815,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     if (!h->adam_ticked) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);     // gradients that did not come from fb_qnet_train_step
     h->adam_ticked = false;
     hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
-                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0], 0, 0);
+                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0], 0, 0, ADAM_GRID, FbGatherRider{});
     h->wsp_stale[0] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
@@ -1836,11 +1852,12 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
 }
 
 int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
-                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, void *stream) {
+                             const uint8_t *t, double gamma, float *loss, const FbSampleRider *rider, const FbGatherRider *gather,
+                             void *stream) {
     Plan p;
     int rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, gamma, loss, nullptr, nullptr, nullptr, &p);
     if (rc != FB_OK) return rc;
-    p.sample_rider = rider;
+    p.sample_rider = rider; p.gather_rider = gather;
     return run_plan(h, p, -1, fb_stream(stream));
 }
 

@@ -51,6 +51,7 @@ struct ReplayParams {
 };
 
 #include "fb_sampler.h"
+#include "fb_gather.h"
 static_assert(MAXB == FB_SAMPLE_MAXB, "sampler batch limit");
 
 __device__ __forceinline__ size_t frame_off(const ReplayParams &P, long long f, int e) {
@@ -103,11 +104,9 @@ __global__ __launch_bounds__(64) void push_kernel(ReplayParams P, long long step
     if (blockIdx.x == 0 && lane == 0) P.dev->steps = steps + 1;
 }
 
-// ------------------------------------------------------------------ gather (minibatch assembly)
-// One thread expands 4 pixels x 4 stacked frames = 16 contiguous bytes of s (and of s').
-__device__ __forceinline__ uint32_t expand4(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, int q) {
-    return (((n0 >> q) & 1u) * 0xFFu) | (((n1 >> q) & 1u) * 0xFF00u) | (((n2 >> q) & 1u) * 0xFF0000u) |
-           (((n3 >> q) & 1u) * 0xFF000000u);
+// ------------------------------------------------------------------ gather (minibatch assembly): fb_gather.h
+__host__ __device__ __forceinline__ FbGatherCtx gather_ctx(const ReplayParams &P) {
+    return FbGatherCtx{P.cap, P.n_envs, P.t_f, P.kind, P.bits, P.act, P.rew, P.term, &P.dev->error};
 }
 
 template <bool CURRENT>
@@ -115,48 +114,7 @@ __global__ __launch_bounds__(256) void gather_kernel(ReplayParams P, long long s
                                                      uint4 *__restrict__ s, uint4 *__restrict__ s2,
                                                      uint8_t *__restrict__ a, float *__restrict__ r,
                                                      uint8_t *__restrict__ t) {
-    // `steps` (pushes so far) comes by value from the host's mirror: one dependent global round trip less than reading
-    // ReplayDev::steps here
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= (long long)B * 1600) return;
-    const int b = (int)(tid / 1600), chunk = (int)(tid - (long long)b * 1600);
-    long long tt; int e;
-    if (CURRENT) { tt = steps; e = b; }
-    else {
-        const long long total = steps * P.n_envs;
-        long long g;
-        if (P.kind == FB_REPLAY_PER) {
-            long long d = idx[b] - (P.cap - 1);
-            if (d < 0 || d >= P.cap || d >= total) { if (chunk == 0) P.dev->error = 1; d = 0; }
-            g = d + P.cap * ((total - 1 - d) / P.cap);  // newest transition living in data slot d
-        } else {
-            const long long size = total < P.cap ? total : P.cap;
-            long long j = idx[b];
-            if (j < 0 || j >= size) { if (chunk == 0) P.dev->error = 1; j = 0; }
-            g = total - size + j;                       // deque position j, 0 = oldest
-        }
-        tt = g / P.n_envs; e = (int)(g - tt * P.n_envs);
-    }
-    const int p = chunk * 4, w = p >> 6, sh = p & 63;
-    uint32_t n[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        if (CURRENT && k == 4) { n[k] = 0; break; }
-        n[k] = (uint32_t)(P.bits[frame_off(P, tt - 3 + k, e) + w] >> sh) & 0xFu;
-    }
-    uint4 o;
-    o.x = expand4(n[0], n[1], n[2], n[3], 0); o.y = expand4(n[0], n[1], n[2], n[3], 1);
-    o.z = expand4(n[0], n[1], n[2], n[3], 2); o.w = expand4(n[0], n[1], n[2], n[3], 3);
-    s[tid] = o;
-    if (!CURRENT) {
-        o.x = expand4(n[1], n[2], n[3], n[4], 0); o.y = expand4(n[1], n[2], n[3], n[4], 1);
-        o.z = expand4(n[1], n[2], n[3], n[4], 2); o.w = expand4(n[1], n[2], n[3], n[4], 3);
-        s2[tid] = o;
-        if (chunk == 0) {
-            const size_t mo = (size_t)(tt % P.t_f) * P.n_envs + e;
-            a[b] = P.act[mo]; r[b] = P.rew[mo]; t[b] = P.term[mo];
-        }
-    }
+    gather_body<CURRENT>(gather_ctx(P), steps, B, idx, s, s2, a, r, t, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------ MT19937 on one wave + random.sample: fb_sampler.h
@@ -668,6 +626,14 @@ int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
     push->act = P.act + mo; push->rew = P.rew + mo; push->term = P.term + mo;
     push->steps_dev = &P.dev->steps; push->steps_new = steps + 1;
     h->host_steps += 1;
+    return 1;
+}
+
+int fb_replay_gather_rider(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r, uint8_t *t,
+                           FbGatherRider *rider) {
+    if (!h || !idx || !s || !s2 || !a || !r || !t || batch < 1) return 0;
+    rider->c = gather_ctx(h->P); rider->steps = h->host_steps; rider->B = batch; rider->idx = (const long long *)idx;
+    rider->s = s; rider->s2 = s2; rider->a = a; rider->r = r; rider->t = t;
     return 1;
 }
 

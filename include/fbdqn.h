@@ -275,8 +275,8 @@ int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_b
                 float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);
 
 /* n_steps x (fb_replay_sample -> fb_replay_gather -> fb_qnet_train_step) on a uniform memory in ONE call, same results: only
- * the first draw is a launch of its own, the draw of step i + 1 rides in step i's conv3 backward launch (CPython generator;
- * other generators keep their launch).  idx: i64[2 * batch] [dev], two buffers used alternately (step i: idx + (i & 1) * batch);
+ * the first draw and the first gather are launches of their own, the draw of step i + 1 rides in step i's conv3 backward
+ * launch and its gather in step i's Adam launch (CPython generator; other generators keep their launches).  idx: i64[2 * batch] [dev], two buffers used alternately (step i: idx + (i & 1) * batch);
  * s, s2, a, r, t, loss as in fb_qnet_train_step. */
 int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int batch, int n_steps, int64_t *idx, uint8_t *s, uint8_t *s2,
                    uint8_t *a, float *r, uint8_t *t, float *loss, double gamma, void *stream);
