@@ -1,5 +1,6 @@
 // MT19937 on one wave and CPython's random.sample on top of it -- device code shared by the replay kernels
-// (fb_replay.hip) and the env step kernel, which can carry the sampler as a rider (fb_env.hip, fb_vec_step).
+// (fb_replay.hip) and the two launches that can carry the sampler as a rider: the env step (fb_env.hip, fb_vec_step) and the
+// conv3 backward (fb_qnet.hip, fb_train_steps).
 // Included inside each translation unit's anonymous namespace.
 #pragma once
 
