@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dqnflappybird_amd import _lib as L
+if os.environ.get("FB_LIB"):                      # an ablation / tuning build of the library
+    L.LIB_PATH = os.path.abspath(os.environ["FB_LIB"])
 from dqnflappybird_amd.vec import QNet
 lib = L.lib()
 R = 100
