@@ -39,6 +39,22 @@ SAVER_ITER = 10000
 RECORD_STEP = (500000, 1000000, 1500000, 2000000, 2500000)
 
 
+class _ScalarUnpickler(pickle.Unpickler):
+    """bird-saved-parameters.txt holds three pickled scalars (reference :230-232).  A pickle can name any
+    callable; this one may name none, so a saved_parameters directory from anywhere (the file format is the
+    reference's) cannot run code here."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"saved parameters may only hold plain numbers, not {module}.{name}")
+
+
+def _load_scalar(f):
+    v = _ScalarUnpickler(f).load()
+    if isinstance(v, bool) or not isinstance(v, (int, float)):
+        raise pickle.UnpicklingError(f"saved parameters may only hold plain numbers, not {type(v).__name__}")
+    return v
+
+
 class BrainDQN:
     ALGO = "dqn"            # -> fb_qnet_train_step algo
     ARCH = "plain"
@@ -115,10 +131,10 @@ class BrainDQN:
         if self.verbose:
             print("Successfully loaded:", ckpt)
         if os.path.exists(self.saved_parameters_file_path) and os.path.getsize(self.saved_parameters_file_path) > 0:
-            with open(self.saved_parameters_file_path, 'rb') as f:      # own files only (see save_checkpoint)
-                self.gameTimes = pickle.load(f)
-                self.timeStep = pickle.load(f)
-                self.epsilon = pickle.load(f)
+            with open(self.saved_parameters_file_path, 'rb') as f:      # three plain numbers, nothing executable
+                self.gameTimes = _load_scalar(f)
+                self.timeStep = _load_scalar(f)
+                self.epsilon = _load_scalar(f)
         return True
 
     def save_checkpoint(self):

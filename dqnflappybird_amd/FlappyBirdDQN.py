@@ -67,10 +67,14 @@ def main():
     parser.add_argument("--vec", type=int, default=0, help="run N vectorised envs (device-resident loop)")
     args = parser.parse_args()
     if args.vec:
+        # one process per GPU (python -m torch.distributed.run --nproc-per-node N -m dqnflappybird_amd.FlappyBirdDQN ...):
+        # --vec envs PER RANK, rank-local replay, one RCCL all-reduce of the flat gradient per train step
+        from . import dist as fdist
         from .vecbrain import VecBrain
+        rank, _, world = fdist.init()
         algo = {"dqn": "dqn", "ddqn": "nature", "dqnnature": "nature", "duelingdqn": "nature", "prioritydqn": "per"}[args.model]
-        vb = VecBrain(args.vec, algo=algo)
-        vb.run(args.steps or 1000, log_every=0 if args.quiet else 100)
+        vb = VecBrain(args.vec, algo=algo, rank=rank, world=world)
+        vb.run(args.steps or 1000, log_every=0 if (args.quiet or rank) else 100)
     else:
         playFlappyBird(args.model, args.steps, verbose=not args.quiet)
 

@@ -85,6 +85,11 @@ struct FbPushRider { unsigned long long *bits; uint8_t *act; float *rew; uint8_t
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream);
 int fb_qnet_num_actions(fb_qnet_t h);
+// argument checks fb_vec_step makes BEFORE any counter moves or any launch goes out (0 = fine, else the error code with
+// fb_last_error set): the batch the train step would reject / the env count the acting forward would reject
+int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch);
+int fb_env_num_envs(fb_env_t h);
+int fb_replay_num_envs(fb_replay_t h);
 int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,

@@ -81,6 +81,17 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     FB_REQUIRE(env && replay && net && b, "fb_vec_step: NULL handle");
     FB_REQUIRE(b->nib && b->actions && b->frame_bits && b->reward && b->terminal && b->score, "fb_vec_step: NULL env buffer");
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
+    // every argument check of the calls below happens HERE, before the replay's push counter moves or anything is launched: a
+    // rejected step must leave the handles exactly as they were (a counted push without its env launch would make every later
+    // gather address a ring slot that was never written)
+    FB_REQUIRE(algo >= 0 && algo <= 3, "fb_vec_step: unknown algo %d", algo);
+    FB_REQUIRE(n_envs == fb_env_num_envs(env) && n_envs == fb_replay_num_envs(replay), "fb_vec_step: n_envs %d does not match the env (%d) / replay (%d) handles",
+               n_envs, fb_env_num_envs(env), fb_replay_num_envs(replay));
+    if (train) FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
+    {
+        const int rc0 = fb_qnet_check_step(net, n_envs, train ? batch : -1);
+        if (rc0 != FB_OK) return rc0;
+    }
     // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
     // every env has a workgroup of its own there
     FbHeadRider hrider;
@@ -92,7 +103,6 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // Riders of the env launch (uniform memory): random.sample of this step -- it only needs the size the memory will have
     // after the push, not the frames -- and the push itself: every env workgroup stores its transition straight into the
     // ring.  Memories that cannot ride keep their own launches (same results).
-    if (train) FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
     FbSampleRider srider;
     FbPushRider prider;
     const int have_s = train ? fb_replay_sample_rider(replay, batch, b->idx, &srider) : 0;      // before the push is counted

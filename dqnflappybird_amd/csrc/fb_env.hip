@@ -471,7 +471,7 @@ int host_gray_bit(uint32_t s00, uint32_t s01, uint32_t s10, uint32_t s11, int a0
 struct fb_env {
     EnvParams p;
     EnvConst *d_const;
-    int8_t *d_tape;
+    int8_t *d_tape; size_t tape_bytes;
     int grid;
 };
 
@@ -612,6 +612,7 @@ extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, 
 }
 
 int fb_env_can_carry_head(fb_env_t h) { return h && h->grid == h->p.n_envs; }
+int fb_env_num_envs(fb_env_t h) { return h ? h->p.n_envs : 0; }
 
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream) {
@@ -662,11 +663,16 @@ extern "C" int fb_env_set_state(fb_env_t h, const int32_t *state_host) {
 extern "C" int fb_env_set_gap_tape(fb_env_t h, const int8_t *tape_host, int tape_len) {
     FB_REQUIRE(h && tape_len >= 0 && (tape_len == 0 || tape_host), "fb_env_set_gap_tape: bad argument");
     FB_CHECK_HIP(hipDeviceSynchronize());
-    if (h->d_tape) { (void)hipFree(h->d_tape); h->d_tape = nullptr; }
+    // the single-env GameState shim hands over a fresh 3-entry tape before every frame_step: keep the allocation while the
+    // size fits and only copy
+    const size_t n = (size_t)h->p.n_envs * tape_len;
     h->p.tape = nullptr; h->p.tape_len = 0;
     if (tape_len > 0) {
-        size_t n = (size_t)h->p.n_envs * tape_len;
-        FB_CHECK_HIP(hipMalloc(&h->d_tape, n));
+        if (n > h->tape_bytes) {
+            if (h->d_tape) { (void)hipFree(h->d_tape); h->d_tape = nullptr; h->tape_bytes = 0; }
+            FB_CHECK_HIP(hipMalloc(&h->d_tape, n));
+            h->tape_bytes = n;
+        }
         FB_CHECK_HIP(hipMemcpy(h->d_tape, tape_host, n, hipMemcpyHostToDevice));
         h->p.tape = h->d_tape; h->p.tape_len = tape_len;
     }

@@ -216,9 +216,11 @@ __device__ __forceinline__ void split_w1(const float w, int idx /* flat index in
     w1s[o] = (uint16_t)hi; w1s[8192 + o] = (uint16_t)mid; w1s[16384 + o] = (uint16_t)lo;
 }
 
-__global__ void w1_split_kernel(const float *__restrict__ params, uint16_t *__restrict__ w1s) {
+// (runs whenever the host replaced a net's parameters: it also bumps that net's parameter version, see AdamDev)
+__global__ void w1_split_kernel(const float *__restrict__ params, uint16_t *__restrict__ w1s, unsigned *__restrict__ pver) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 8192) split_w1(params[OFF_W1 + idx], idx, w1s);
+    if (idx == 0 && pver) *pver += 1;
 }
 
 __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
@@ -465,7 +467,10 @@ __device__ __forceinline__ void wsplit_item(const float *__restrict__ params, ui
     o[2 * N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC) {
+// stand-alone re-split (the acting forward normally does it inside its conv1 launch): only when the versions differ
+__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, const unsigned *__restrict__ pver,
+                              const unsigned *__restrict__ wver) {
+    if (*pver == *wver) return;
     wsplit_item(params, wsp, FC, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -497,7 +502,8 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int l) {
 
 template <bool NIB>
 __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
-                                                                  size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC, int resplit) {
+                                                                  size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC,
+                                                                  const unsigned *__restrict__ pver, const unsigned *__restrict__ wver) {
     __shared__ uint4 wl[3 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
     const int bid = blockIdx.x, nblk = gridDim.x;
@@ -506,7 +512,9 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
     uint4 wcopy[WC];
 #pragma unroll
     for (int u = 0; u < WC; u++) { const int q = threadIdx.x + u * 64 * C1_WAVES; wcopy[u] = reinterpret_cast<const uint4 *>(s.w1s)[q < WQ ? q : 0]; }
-    if (resplit) {
+    // the parameters changed since wsp was split (decided here, on the device: a replayed hipGraph takes the same decision a
+    // live call would); the conv2+conv3 launch that follows records the new version
+    if (pver && *pver != *wver) {
         const int items = 64 * 64 + 72 * 64 + 200 * FC;
         for (int id = blockIdx.x * (64 * C1_WAVES) + threadIdx.x; id < items; id += gridDim.x * (64 * C1_WAVES)) wsplit_item(s.params, wsp, FC, id);
     }
@@ -612,6 +620,7 @@ struct C23Args {
     const float *b2, *b3;
     uint16_t *a3s; size_t pl3;               // conv3 output planes [3][n*25][64]
     int n;
+    const unsigned *pver; unsigned *wver;    // whole forward plans: the conv1 launch in front re-split the weights if these differed
 };
 
 #ifndef C23_NO_LDSR
@@ -629,6 +638,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     __shared__ uint4 smem[RING + 3 * RSZ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
     const int s0 = blockIdx.x * 5, ml = wave * 32 + j;
+    if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) *a.wver = *a.pver;
     const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
     const bool rowok = ml < 125;
     int nloc = a.n - s0; if (nloc > 5) nloc = 5;
@@ -927,7 +937,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
 }
 
 // ================================================================== loss + head backward
-struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; };
+// Device-resident optimizer / parameter-version state.  Everything that decides WHAT a later launch has to do lives here and
+// not in the host handle, so a step replayed from a captured hipGraph leaves the same state behind as a live one:
+//   ticks / applies   Adam step counter bookkeeping: the loss kernel advances beta1^t / beta2^t (a "tick") only when the previous
+//                     tick has been consumed by an Adam update (ticks == applies); the Adam kernel marks it consumed
+//   pver / wver       version of the parameters of net 0 / 1 (bumped by whatever writes them: Adam, init, load, target sync) and
+//                     the version the bf16 hi/mid/lo split of W_conv2 / W_conv3 / W_fc1 (wsp) was built from; the acting forward
+//                     compares the two ON THE DEVICE and re-splits when they differ
+struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; int ticks, applies; unsigned pver[2], wver[2]; };
 
 struct LossArgs {
     int algo, B, FC, A, dueling;
@@ -1032,10 +1049,11 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
         float s = 0.f;
         for (int b = 0; b < B; b++) s += lterm[b];
         *L.loss = L.algo == FB_ALGO_DQN ? s : s / (float)B;
-        if (L.tick) {                                            // Adam step counter for the update that follows
-            AdamDev &ad = *L.adam;
+        if (L.tick && L.adam->ticks == L.adam->applies) {        // Adam step counter for the update that follows (at most one
+            AdamDev &ad = *L.adam;                               // tick per update: a second gradient pass before the apply re-uses it)
             ad.alpha = ad.lr * sqrtf(1.f - ad.b2pow) / (1.f - ad.b1pow);
             ad.b1pow *= ad.b1; ad.b2pow *= ad.b2;
+            ad.ticks += 1;
         }
     }
     if (lead && tid >= 64 && tid < 64 + A) { const int a = tid - 64; float s = 0.f; for (int b = 0; b < B; b++) s += dadv[b][a]; L.grad[L.off.bq + a] = s; }
@@ -1089,10 +1107,15 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     else loss_head_body<MAXA>(L, dadv, dv, lterm, part);
 }
 
+// fb_qnet_apply_adam on gradients that no fb_qnet_train_step ticked for (guarded on the device, so it is safe to launch always)
 __global__ void adam_tick_kernel(AdamDev *ad) {
+    if (ad->ticks != ad->applies) return;
     ad->alpha = ad->lr * sqrtf(1.f - ad->b2pow) / (1.f - ad->b1pow);
     ad->b1pow *= ad->b1; ad->b2pow *= ad->b2;
+    ad->ticks += 1;
 }
+__global__ void bump_pver_kernel(AdamDev *ad, int which) { ad->pver[which] += 1; }
+__global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad->pver[which]; }
 
 // ================================================================== backward
 // dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
@@ -1378,7 +1401,7 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_
 // TF ApplyAdam, fp32, float4 wide.  When `slabs` is given the conv gradients are still spread over the
 // reduction slabs of conv_dw_kernel: they are summed here, in slab order, instead of in a separate launch.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
-                                                   const float *__restrict__ g, long long n, const AdamDev *__restrict__ ad,
+                                                   const float *__restrict__ g, long long n, AdamDev *__restrict__ ad,
                                                    const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
                                                    uint16_t *__restrict__ w1s, int skip0, int skip1, int n_adam_blocks,
                                                    FbGatherRider gr) {
@@ -1411,6 +1434,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
             split_w1(P.x, idx, w1s); split_w1(P.y, idx + 1, w1s); split_w1(P.z, idx + 2, w1s); split_w1(P.w, idx + 3, w1s);
         }
     }
+    // the update consumes the pending tick and makes a new parameter version (nothing in this launch reads either word)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ad->applies = ad->ticks; ad->pver[0] += 1; }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long q = (n4 << 2) + threadIdx.x;
         float mm = m[q], vv = v[q];
@@ -1452,11 +1477,11 @@ struct fb_qnet {
     float *slabs1;                   // conv1 sub-slabs of large batches (slab_fold_kernel), NULL when max_batch never needs them
     uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
     uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
-    bool wsp_stale[2];               // parameters changed since wsp was built
     uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
     uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [3][S*3200], conv3 out [3][S*1600] bf16
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
-    bool adam_ticked;                // a data-parallel train step already advanced beta1^t / beta2^t for the apply_adam that follows
+    bool adam_ticked;                // host-side hint only (eager calls): the last train step left a tick pending for fb_qnet_apply_adam;
+                                     // the truth is AdamDev::ticks / applies on the device
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
@@ -1497,7 +1522,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
     const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)(200 + 4) * 3 * fc_width) * sizeof(uint4);   // + one chunk: fc1_sp_kernel over-reads
     alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
-    h->wsp_stale[0] = h->wsp_stale[1] = true; h->nsplit = 3;
+    h->nsplit = 3;
     alloc((void **)&h->zeros, 256);
     alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a3s, S * 1600 * 6 + 256);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
@@ -1512,6 +1537,11 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
         return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
     }
     *out = h;
+    {   // wsp has never been split: parameter versions start ahead of the split versions
+        AdamDev a; memset(&a, 0, sizeof(a));
+        a.pver[0] = a.pver[1] = 1;
+        if (hipMemcpy(h->adam, &a, sizeof(a), hipMemcpyHostToDevice) != hipSuccess) { fb_qnet_destroy(h); *out = nullptr; return fb_set_error(FB_ERR_HIP, "fb_qnet_create: hipMemcpy failed"); }
+    }
     return fb_qnet_set_hparams(h, 1e-6f, 0.9f, 0.999f, 1e-8f);
 }
 
@@ -1553,8 +1583,7 @@ extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *
     hipLaunchKernelGGL(init_params_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, fb_stream(stream),
                        h->params[which], h->n, h->off, h->FC, h->A, h->arch == FB_ARCH_DUELING, (uint32_t)seed,
                        (uint32_t)(seed >> 32));
-    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
-    h->wsp_stale[which] = true;
+    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which], &h->adam->pver[which]);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -1562,8 +1591,7 @@ extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *
 extern "C" int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat, void *stream) {
     FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_load_params: bad argument");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[which], flat, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
-    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which]);
-    h->wsp_stale[which] = true;
+    hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which], &h->adam->pver[which]);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -1637,28 +1665,23 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
     // stale split weights: refreshed by the leading workgroups of the conv1 launch (or by a launch of their own when
     // only a later kernel of the plan is requested)
-    int nws = 0;
-    if (sp && h->wsp_stale[p.which]) {
-        if (only < 0 || only == K_CONV1) nws = 1;
-        else {
-            const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
-            hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, p.sl.s[0].params, h->wsp[p.which], h->FC);
-        }
-        h->wsp_stale[p.which] = false;
-    }
+    // (decided on the device from AdamDev::pver / wver; a single profiled kernel never re-splits: fb_qnet_profile_kernel
+    // brings wsp up to date once, in front of its loop)
+    const unsigned *pver = sp && only < 0 ? &h->adam->pver[p.which] : nullptr;
+    unsigned *wver = sp && only < 0 ? &h->adam->wver[p.which] : nullptr;
     FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
         if (sp) {
             // persistent: one 12-wave workgroup per CU, the waves stride over the tiles
             const int gsp = min(256, (t1 + C1_WAVES - 1) / C1_WAVES);
-            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
-            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, nws);
+            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, pver, (const unsigned *)wver);
+            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, pver, (const unsigned *)wver);
         } else if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
         else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
     const int stot = 3 * h->max_batch;
     if (sp) {
-        C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc};
+        C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc, pver, wver};
         Fc1Args af{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, h->hf, stot, maxc, h->FC};
         const dim3 gc((maxc + 4) / 5), gf(((maxc + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
         if (h->nsplit == 3) {
@@ -1702,9 +1725,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             // data-parallel path: the loss kernel advances the Adam step counter as well (once per fb_qnet_apply_adam), so the
             // apply needs no launch of its own for it
-            const bool tick = p.tick && !h->adam_ticked;            // at most one tick per Adam update
+            // (at most one tick per Adam update: guarded on the device by AdamDev::ticks / applies)
             if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
-            L.adam = h->adam; L.tick = tick;
+            L.adam = h->adam; L.tick = p.tick;
             hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
         }
         // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
@@ -1748,7 +1771,6 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             hipLaunchKernelGGL(adam_kernel, dim3(nab + ngb), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G,
                                h->n, h->adam, (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0], span0, span1, nab, gr);
         }
-        if (p.apply_adam && (only < 0 || only == K_ADAM)) h->wsp_stale[0] = true;
     }
 #undef FB_K
     FB_LAUNCH_CHECK();
@@ -1798,6 +1820,14 @@ extern "C" int fb_qnet_act_nib(fb_qnet_t h, const uint8_t *nib_states, int n, fl
 
 int fb_qnet_num_actions(fb_qnet_t h) { return h ? h->A : 0; }
 
+int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch) {
+    FB_REQUIRE(h, "fb_vec_step: NULL net");
+    FB_REQUIRE(n_envs >= 1 && n_envs <= 3 * h->max_batch, "fb_vec_step: %d envs exceed 3*max_batch of the net", n_envs);
+    FB_REQUIRE(train_batch < 0 || (train_batch >= 1 && train_batch <= h->max_batch && train_batch <= MAXTB),
+               "fb_vec_step: batch %d exceeds min(max_batch, %d)", train_batch, MAXTB);
+    return FB_OK;
+}
+
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                           uint8_t *actions, FbHeadRider *head, void *stream) {
     FB_REQUIRE(h && nib_states && actions && head, "fb_qnet_act_nib_rider: NULL argument");
@@ -1812,11 +1842,15 @@ int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float e
 extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream) {
     FB_REQUIRE(h && flat_grad, "fb_qnet_apply_adam: NULL argument");
     hipStream_t st = fb_stream(stream);
-    if (!h->adam_ticked) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);     // gradients that did not come from fb_qnet_train_step
+    // gradients that did not come from fb_qnet_train_step need their own tick.  The kernel checks on the device whether one is
+    // pending; the host-side hint only saves the launch in eager mode (under stream capture the hint describes capture time, not
+    // replay time, so the guarded kernel always goes in)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (!h->adam_ticked || cap != hipStreamCaptureStatusNone) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
     h->adam_ticked = false;
     hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
                        (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0], 0, 0, ADAM_GRID, FbGatherRider{});
-    h->wsp_stale[0] = true;
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -1825,7 +1859,8 @@ extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     FB_REQUIRE(h, "fb_qnet_sync_target: NULL handle");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[1], h->params[0], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
     FB_CHECK_HIP(hipMemcpyAsync(h->w1s[1], h->w1s[0], 3 * 8192 * 2, hipMemcpyDeviceToDevice, fb_stream(stream)));
-    h->wsp_stale[1] = true;
+    hipLaunchKernelGGL(bump_pver_kernel, dim3(1), dim3(1), 0, fb_stream(stream), h->adam, 1);
+    FB_LAUNCH_CHECK();
     return FB_OK;
 }
 
@@ -1886,6 +1921,12 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
     } else rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, 0.99, loss, nullptr, nullptr, nullptr, &p);
     if (rc != FB_OK) return rc;
     p.tick = false;
+    if (algo < 0 && B >= 256) {                  // the split-bf16 path: bring wsp up to date once, outside the timed launches
+        const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
+        hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, fb_stream(stream), h->params[0], h->wsp[0], h->FC,
+                           (const unsigned *)&h->adam->pver[0], (const unsigned *)&h->adam->wver[0]);
+        hipLaunchKernelGGL(mark_split_kernel, dim3(1), dim3(1), 0, fb_stream(stream), h->adam, 0);
+    }
     for (int i = 0; i < reps; i++) { rc = run_plan(h, p, kernel, fb_stream(stream)); if (rc != FB_OK) return rc; }
     return FB_OK;
 }

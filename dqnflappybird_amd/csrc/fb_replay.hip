@@ -617,6 +617,8 @@ extern "C" int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const
     return FB_OK;
 }
 
+int fb_replay_num_envs(fb_replay_t h) { return h ? h->P.n_envs : 0; }
+
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
     ReplayParams &P = h->P;
     if (P.kind != FB_REPLAY_UNIFORM) return 0;

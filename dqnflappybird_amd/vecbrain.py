@@ -8,31 +8,61 @@ Host-side schedule follows the reference: training starts once onlineTimeStep > 
 decays by (INITIAL - FINAL) / EXPLORE per step after that, Nature/Double sync the target net when
 timeStep % 500 == 0, PER never does.
 """
-import torch
-
 from . import dist as fdist
-from .vec import QNet, VecGameState, VecReplay, VecStep
 
 MEAN_LOSS = {"dqn": False, "nature": True, "double": True, "per": True}
+
+
+class HipVecBackend:
+    """What VecBrain computes with: the HIP library through vec.py.  (tests/cpu_backend.py holds a CPU stand-in with the
+    same five factories, so that the rank logic below -- seed offsets, gradient averaging, target-sync placement -- runs
+    in the world-size-2 gloo tests without a GPU; the product never uses anything else than this class.)"""
+    name = "hip-gfx950"
+
+    def env(self, n_envs, seed):
+        from .vec import VecGameState
+        return VecGameState(n_envs, seed=seed)
+
+    def replay(self, capacity, n_envs, prioritized):
+        from .vec import VecReplay
+        return VecReplay(capacity, n_envs, prioritized=prioritized)
+
+    def net(self, actions, fc_width, arch, max_batch):
+        from .vec import QNet
+        return QNet(actions, fc_width, arch, max_batch=max_batch)
+
+    def step(self, env, replay, net, batch, algo, gamma, flat_grad):
+        from .vec import VecStep
+        return VecStep(env, replay, net, batch, algo, gamma, flat_grad=flat_grad)
+
+    def zeros(self, n):
+        import torch
+        return torch.zeros(n, dtype=torch.float32, device="cuda")
 
 
 class VecBrain:
     def __init__(self, n_envs, algo="dqn", arch="plain", batch=32, capacity=1_000_000, fc_width=512, seed=0,
                  observe=1000, explore=1_000_000, initial_epsilon=0.03, final_epsilon=0.0, gamma=0.99,
-                 replace_target_iter=500, sampler=None, rank=0, world=1):
+                 replace_target_iter=500, sampler=None, rank=0, world=1, backend=None):
+        be = backend or HipVecBackend()
         self.n, self.algo, self.batch, self.gamma = n_envs, algo, batch, gamma
         self.rank, self.world = rank, world
         self.observe, self.explore = observe, explore
         self.epsilon, self.initial_epsilon, self.final_epsilon = initial_epsilon, initial_epsilon, final_epsilon
         self.replace_target_iter = replace_target_iter
         self.seed = seed
-        self.env = VecGameState(n_envs, seed=seed + 1000003 * rank)
-        self.replay = VecReplay(capacity, n_envs, prioritized=(algo == "per"))
+        self.env = be.env(n_envs, seed + 1000003 * rank)     # envs shard by rank: every rank plays its own games
+        self.replay = be.replay(capacity, n_envs, algo == "per")     # ... into its own replay shard
         self.replay.seed(seed + rank, sampler)
-        self.net = QNet(2, fc_width, arch, max_batch=max(n_envs, batch))
+        self.net = be.net(2, fc_width, arch, max(n_envs, batch))
         self.net.init_params(seed=seed, which=0)             # the same draw on every rank
         self.net.init_params(seed=seed + 1, which=1)
-        self.grad = torch.zeros(self.net.n_params, dtype=torch.float32, device="cuda") if world > 1 else None
+        if world > 1:                                        # replicas start from rank 0's parameters, bit for bit
+            for which in (0, 1):
+                flat = self.net.store_params(which)
+                fdist.broadcast_params(flat, src=0)
+                self.net.load_params(flat, which)
+        self.grad = be.zeros(self.net.n_params) if world > 1 else None
         self.timeStep = 0
         self.onlineTimeStep = 0
         self.nib = self.env.track_state()                    # currentState of every env, maintained by the env kernel
@@ -42,7 +72,7 @@ class VecBrain:
         self.last_loss = None
         # uniform replay: the whole step is one host call (fb_vec_step), with the head, random.sample and the Memory append
         # riding in the env launch; PER keeps the separate calls (its sample returns the importance weights)
-        self.one_step = VecStep(self.env, self.replay, self.net, batch, algo, gamma, flat_grad=self.grad) if algo != "per" else None
+        self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad) if algo != "per" else None
 
     def train_step(self, idx=None):
         if self.algo in ("nature", "double") and self.timeStep % self.replace_target_iter == 0:

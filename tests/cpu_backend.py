@@ -123,3 +123,131 @@ class CpuBackend:
     @staticmethod
     def host(t):
         return np.asarray(t)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CPU stand-ins for the vectorised loop (dqnflappybird_amd.vecbrain.HipVecBackend), tests only: N oracle envs, the deque N envs
+# appending in env order build, CPython's random.sample, the oracle network.  They mirror what fb_vec_step does per step so
+# that VecBrain's rank logic (env / replay / acting seeds per rank, gradient sum vs mean over ranks, target-sync placement,
+# parameter broadcast) runs under a world-size-2 gloo group without a GPU.
+class CpuVecEnv:
+    def __init__(self, n_envs, seed):
+        self.n, self.seed = n_envs, seed
+        self.envs = [o.GameState(seed=seed, env_id=e) for e in range(n_envs)]
+        self.frame_bits = None
+        self.episodes = 0
+
+    def track_state(self):
+        return None
+
+    def track_stats(self):
+        return np.zeros(4, np.int64)
+
+    def observe(self):
+        self.frame_bits = np.stack([g.frame80() for g in self.envs])
+        return self.frame_bits
+
+    def step(self, actions):
+        out = [g.step(int(a)) for g, a in zip(self.envs, actions)]
+        self.frame_bits = np.stack([g.frame80() for g in self.envs])
+        self.reward = np.array([x[0] for x in out], np.float32)
+        self.terminal = np.array([x[1] for x in out], np.uint8)
+        return self.frame_bits, self.reward, self.terminal
+
+
+class CpuVecReplay:
+    """uniform memory of N envs: one transition per env and step, appended in env order (fb_replay.hip's deque order)"""
+
+    def __init__(self, capacity, n_envs, prioritized):
+        assert not prioritized
+        self.cap, self.n = capacity, n_envs
+        self.mem, self.states, self.rng = [], None, None
+
+    def seed(self, seed, rng=None):
+        self.rng = o.PyRandom(seed)
+
+    def reset(self, frames):
+        self.states = [np.stack([f] * 4, axis=2) for f in frames]
+        self.mem = []
+
+    def current_state(self):
+        return np.stack(self.states)
+
+    def push(self, frames, a, r, t):
+        for e in range(self.n):
+            new = np.append(self.states[e][:, :, 1:], frames[e].reshape(80, 80, 1), axis=2)
+            self.mem.append((self.states[e], int(a[e]), float(r[e]), new, int(t[e])))
+            self.states[e] = new
+        del self.mem[:max(0, len(self.mem) - self.cap)]
+
+    def sample(self, batch):
+        return self.rng.sample(len(self.mem), batch)
+
+    def gather(self, idx):
+        trs = [self.mem[int(i)] for i in idx]
+        return (np.stack([x[0] for x in trs]), np.array([x[1] for x in trs], np.uint8), np.array([x[2] for x in trs], np.float32),
+                np.stack([x[3] for x in trs]), np.array([x[4] for x in trs], np.uint8))
+
+
+class CpuVecNet(CpuNet):
+    """CpuNet speaking torch CPU tensors at its boundary (what torch.distributed moves)"""
+
+    def store_params(self, which=0):
+        import torch
+        return torch.from_numpy(self.p[which].copy())
+
+    def load_params(self, flat, which=0):
+        self.p[which] = np.array(flat, np.float32)
+
+    def apply_adam(self, g):
+        self.opt.step(self.p[0], np.asarray(g, np.float32))
+
+
+class CpuVecStep:
+    """fb_vec_step on the stand-ins: act (Q + the Philox epsilon-greedy stream of fb_head.h) -> step -> store ->
+    random.sample -> gather -> train"""
+
+    def __init__(self, env, replay, net, batch, algo, gamma, flat_grad):
+        self.env, self.replay, self.net = env, replay, net
+        self.batch, self.algo, self.gamma, self.flat_grad = batch, algo, gamma, flat_grad
+        self.loss, self.idx, self.actions = None, None, None
+
+    def __call__(self, epsilon, seed=0, step=0, train=True):
+        q = self.net.forward(self.replay.current_state())
+        acts = np.argmax(q, axis=1).astype(np.uint8)
+        for e in range(self.env.n):
+            ph = o.philox(seed & 0xFFFFFFFF, seed >> 32, e, step & 0xFFFFFFFF, 1, step >> 32)      # FB_STREAM_EPS
+            u = np.float32(int(ph[0]) >> 8) * np.float32(1.0 / 16777216.0)
+            if u <= np.float32(epsilon):
+                acts[e] = (int(ph[1]) * 2) >> 32
+        frames, r, t = self.env.step(acts)
+        self.replay.push(frames, acts, r, t)
+        self.actions = acts
+        if train:
+            self.idx = self.replay.sample(self.batch)
+            s, a, r, s2, t = self.replay.gather(self.idx)
+            g = None if self.flat_grad is None else np.empty(self.net.n_params, np.float32)
+            self.loss, _, _ = self.net.train_step(self.algo, s, a, r, s2, t, gamma=self.gamma, flat_grad=g)
+            if g is not None:
+                self.flat_grad.copy_(__import__("torch").from_numpy(g))
+        return acts
+
+
+class CpuVecBackend:
+    name = "cpu-oracle (tests only)"
+
+    def env(self, n_envs, seed):
+        return CpuVecEnv(n_envs, seed)
+
+    def replay(self, capacity, n_envs, prioritized):
+        return CpuVecReplay(capacity, n_envs, prioritized)
+
+    def net(self, actions, fc_width, arch, max_batch):
+        return CpuVecNet(actions, fc_width, arch, max_batch)
+
+    def step(self, env, replay, net, batch, algo, gamma, flat_grad):
+        return CpuVecStep(env, replay, net, batch, algo, gamma, flat_grad)
+
+    def zeros(self, n):
+        import torch
+        return torch.zeros(n, dtype=torch.float32)

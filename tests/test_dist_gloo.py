@@ -67,6 +67,80 @@ def test_two_rank_allreduce_equals_global_batch(tmp_path, mean_loss):
     np.testing.assert_allclose(g0, gref, rtol=1e-4, atol=1e-6 * scale)
 
 
+# ------------------------------------------------------------------ the real VecBrain rank logic, two processes
+VB = dict(n_envs=2, batch=4, capacity=64, fc_width=128, seed=5, observe=2, explore=1000, initial_epsilon=0.25,
+          final_epsilon=0.0, replace_target_iter=3)
+VB_STEPS = 9                                   # observe 3 steps, train 6; timeStep % 3 == 0 syncs the target net twice
+
+
+def _vecbrain_worker(rank, world, port, algo, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from dqnflappybird_amd import dist as fdist
+    from dqnflappybird_amd.vecbrain import VecBrain
+    from tests.cpu_backend import CpuVecBackend
+    r, _, w = fdist.init("gloo")
+    vb = VecBrain(algo=algo, rank=r, world=w, backend=CpuVecBackend(), **VB)
+    trace = []
+    for _ in range(VB_STEPS):
+        vb.step()
+        trace.append(np.concatenate([vb.one_step.actions, vb.one_step.idx if vb.one_step.idx is not None else []]))
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), vb.net.p[0])
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), vb.net.p[1])
+    np.save(os.path.join(out_dir, f"m{rank}.npy"), vb.net.opt.m)
+    np.save(os.path.join(out_dir, f"trace{rank}.npy"), np.concatenate(trace))
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([vb.timeStep, vb.onlineTimeStep, vb.net.syncs, vb.epsilon]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["dqn", "nature"])
+def test_vecbrain_rank_logic_two_processes(tmp_path, algo):
+    """VecBrain(rank, world = 2) through the CPU stand-in backend under gloo: replicas stay bit-identical, the two ranks play
+    DIFFERENT games and draw DIFFERENT minibatches (env / replay / acting seeds are offset by rank), the update equals one
+    optimizer step on the global batch (sum for BrainDQN's sum loss, mean for the mean losses), and the target net syncs on
+    timeStep % replace_target_iter while training."""
+    import torch
+    from dqnflappybird_amd.vecbrain import MEAN_LOSS, VecBrain
+    from tests.cpu_backend import CpuVecBackend
+    port = 29900 + (os.getpid() % 97) + (0 if algo == "dqn" else 100)
+    mp.spawn(_vecbrain_worker, args=(2, port, algo, str(tmp_path)), nprocs=2, join=True)
+    ld = lambda n: [np.load(tmp_path / f"{n}{r}.npy") for r in (0, 1)]
+    p, t, m, trace, meta = ld("p"), ld("t"), ld("m"), ld("trace"), ld("meta")
+    assert np.array_equal(p[0], p[1]) and np.array_equal(t[0], t[1]) and np.array_equal(m[0], m[1])
+    assert not np.array_equal(trace[0], trace[1])                # rank-local envs and replay shards
+    assert np.array_equal(meta[0], meta[1]) and meta[0][0] == VB_STEPS
+    want_syncs = sum(1 for ts in range(VB_STEPS) if ts > VB["observe"] and algo == "nature" and ts % VB["replace_target_iter"] == 0)
+    assert meta[0][2] == want_syncs
+    # the same thing in ONE process: both ranks' brains side by side, gradients combined by hand
+    brains = [VecBrain(algo=algo, rank=r, world=1, backend=CpuVecBackend(), **VB) for r in (0, 1)]
+    for r, b in enumerate(brains):                               # what world = 2 changes in the constructor, by hand
+        b.rank = r
+        b.env = CpuVecBackend().env(VB["n_envs"], VB["seed"] + 1000003 * r)
+        b.replay = CpuVecBackend().replay(VB["capacity"], VB["n_envs"], False)
+        b.replay.seed(VB["seed"] + r)
+        b.env.observe(); b.replay.reset(b.env.frame_bits)
+        b.grad = torch.zeros(b.net.n_params)
+        b.one_step = CpuVecBackend().step(b.env, b.replay, b.net, VB["batch"], algo, b.gamma, b.grad)
+    for step in range(VB_STEPS):
+        training = step > VB["observe"]
+        for b in brains:
+            if training and algo == "nature" and b.timeStep % VB["replace_target_iter"] == 0:
+                b.net.sync_target()
+            b.one_step(b.epsilon, seed=VB["seed"] + b.rank, step=b.timeStep, train=training)
+        if training:
+            g = brains[0].grad + brains[1].grad
+            if MEAN_LOSS[algo]:
+                g = g / 2
+            for b in brains:
+                b.net.apply_adam(g)
+        for b in brains:
+            if b.epsilon > b.final_epsilon and b.onlineTimeStep > b.observe:
+                b.epsilon -= (b.initial_epsilon - b.final_epsilon) / b.explore
+            b.timeStep += 1; b.onlineTimeStep += 1
+    assert np.array_equal(brains[0].net.p[0], p[0]) and np.array_equal(brains[1].net.p[0], p[0])
+    assert np.array_equal(brains[0].net.p[1], t[0])
+
+
 def test_single_process_is_a_no_op():
     from dqnflappybird_amd import dist as fdist
     g = torch.ones(10)

@@ -229,6 +229,113 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("N,steps,algo", [(256, 40, "dqn"), (2304, 24, "nature")])
+def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
+    """The N > 1 hot path at world size 1 (bench.py full_step / VecBrain.step): fb_vec_step(flat_grad = g) followed by
+    fb_qnet_apply_adam(g) == fb_vec_step() with Adam fused, bit for bit and step by step -- actions (so the acting forward
+    saw the weights the stand-alone Adam wrote, re-split into bf16 planes), sampled indices, loss -- and at the end the
+    parameters, both Adam slots and beta powers, the env states and the agents' frame stacks."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    B = 32
+
+    def make(dp):
+        env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+        rep.seed(9, "cpython"); net.init_params(3, which=0); net.init_params(4, which=1)
+        nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
+        grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda") if dp else None
+        return env, rep, net, nib, grad, VecStep(env, rep, net, B, algo, flat_grad=grad)
+
+    e1, r1, n1, nib1, _, fused = make(False)
+    e2, r2, n2, nib2, grad, split = make(True)
+    for step in range(steps):
+        train = step >= 8
+        if train and algo == "nature" and step % 5 == 0:
+            n1.sync_target(); n2.sync_target()
+        a1 = fused(0.05, seed=1, step=step, train=train)
+        a2 = split(0.05, seed=1, step=step, train=train)
+        if train:
+            n2.apply_adam(grad)
+        assert torch.equal(a1, a2), step
+        if train:
+            assert torch.equal(fused.idx, split.idx) and torch.equal(fused.loss, split.loss), step
+    assert (e1.get_state() == e2.get_state()).all() and torch.equal(nib1, nib2)
+    assert torch.equal(n1.store_params(), n2.store_params()) and torch.equal(n1.store_params(1), n2.store_params(1))
+    (m1, v1, p1), (m2, v2, p2) = n1.adam_state(), n2.adam_state()
+    assert torch.equal(m1, m2) and torch.equal(v1, v2) and np.array_equal(p1, p2)
+    assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
+
+
+def test_graph_replayed_train_steps_refresh_the_acting_weights(torch_cuda):
+    """A train step replayed from a captured hipGraph changes the parameters without the host handle noticing: the acting
+    forward on >= 256 states (bf16 hi/mid/lo split of the weights) must still re-split them.  Staleness is decided on the
+    device (AdamDev::pver / wver), so: capture TrainSteps -> act live -> replay -> act == the same sequence run eagerly, bit for
+    bit; and an acting forward captured while the split was fresh re-splits when it is replayed after the parameters moved."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, TrainSteps, VecGameState, VecReplay
+    N, B = 256, 32
+
+    def make():
+        env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+        rep.seed(9, "cpython"); net.init_params(3); net.set_hparams(lr=1e-3)     # steps large enough to move Q visibly
+        nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
+        acts = (torch.rand(N, generator=torch.Generator().manual_seed(1)) < 0.1).to(torch.uint8).cuda()
+        for _ in range(12):
+            env.frame_step(acts, want_u8=False)
+            rep.push(env.frame_bits, acts, env.reward, env.terminal)
+        ts = TrainSteps(rep, net, B, "dqn")
+        ts(1)                                                            # warm-up: every kernel loaded before any capture
+        torch.cuda.synchronize()
+        return env, rep, net, nib, ts
+
+    # eager
+    _, _, n1, nib1, ts1 = make()
+    q1a = n1.act_nib(nib1, 0.0, want_q=True)[1].clone()
+    ts1(2)
+    q1b = n1.act_nib(nib1, 0.0, want_q=True)[1].clone()
+    ts1(2)
+    q1c = n1.act_nib(nib1, 0.0, want_q=True)[1].clone()
+    # graphs
+    _, _, n2, nib2, ts2 = make()
+    g_train, g_act = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_train):
+        ts2(2)
+    q2a = n2.act_nib(nib2, 0.0, want_q=True)[1].clone()                  # live act: the split is fresh from here on
+    g_train.replay()                                                     # parameters move on the device only
+    q2b = n2.act_nib(nib2, 0.0, want_q=True)[1].clone()
+    with torch.cuda.graph(g_act):                                        # captured while the split is fresh
+        q_cap = n2.act_nib(nib2, 0.0, want_q=True)[1]
+    g_train.replay()
+    g_act.replay()
+    torch.cuda.synchronize()
+    q2c = q_cap.clone()
+    assert torch.equal(q1a, q2a) and torch.equal(q1b, q2b) and torch.equal(q1c, q2c)
+    assert not torch.equal(q1a, q1b) and not torch.equal(q1b, q1c)       # the comparison is not vacuous
+    assert torch.equal(n1.store_params(), n2.store_params())
+    m1, v1, p1 = n1.adam_state(); m2, v2, p2 = n2.adam_state()
+    assert torch.equal(m1, m2) and torch.equal(v1, v2) and np.array_equal(p1, p2)
+
+
+def test_vec_step_rejects_bad_arguments_before_anything_moves(torch_cuda):
+    """fb_vec_step validates everything up front: a rejected call leaves the replay's push counter, the env and the
+    network exactly as they were (it used to count the push before the train step refused the batch)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    N = 64
+    env, rep, net = VecGameState(N, seed=5), VecReplay(5000, N), QNet(max_batch=N)
+    rep.seed(9, "cpython"); net.init_params(3)
+    env.track_state(); env.observe(); rep.reset(env.frame_bits)
+    good, bad = VecStep(env, rep, net, 32, "dqn"), VecStep(env, rep, net, 300, "dqn")      # 300 > MAXTB = 256 and > max_batch
+    for step in range(3):
+        good(0.0, step=step, train=False)
+    size, state, params = len(rep), env.get_state().copy(), net.store_params().clone()
+    with pytest.raises(ValueError):
+        bad(0.0, step=3, train=True)
+    assert len(rep) == size and (env.get_state() == state).all() and torch.equal(net.store_params(), params)
+    good(0.0, step=3, train=True)                                        # and the pipeline carries on
+    assert len(rep) == size + N
+
+
 def test_standalone_dueling_recipe_on_device(torch_cuda, tmp_path, monkeypatch):
     """the reference's stand-alone BrainDuelingDQN.py loop end to end on the HIP backend: drop-in game module,
     preprocess kernel, HBM replay, dueling net, checkpoints."""
