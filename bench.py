@@ -254,6 +254,8 @@ def main():
                 break
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, 0, BATCH, L.ptr(s), L.ptr(a), L.ptr(r),
                                                                   L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
+            if us < 0.2:                                     # not a launch of this plan (head / loss ride in the fc1 kernels at B = 32)
+                continue
             if name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
             elif name == "conv3_bwd_kernel":                  # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups

@@ -19,6 +19,14 @@
 #include <stdlib.h>
 #include "fb_common.h"
 
+// ablation switches of the small-batch fc1 kernels (tools/time_train.py against -DFK_ABL=n / -DBW_ABL=n builds; 0 = the product)
+#ifndef FK_ABL
+#define FK_ABL 0
+#endif
+#ifndef BW_ABL
+#define BW_ABL 0
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1117,6 +1125,432 @@ __global__ void adam_tick_kernel(AdamDev *ad) {
 __global__ void bump_pver_kernel(AdamDev *ad, int which) { ad->pver[which] += 1; }
 __global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad->pver[which]; }
 
+// ================================================================== fc1 + loss, small batches (training, < 256 states)
+// fc1 with the WHOLE reduction in one workgroup.  fc1_kernel above splits K = 1600 over 5 workgroups, which leaves five partial
+// sums per unit that only a further launch can add up -- so Q (and with it the loss and every gradient) sat two launches
+// behind fc1 (head_kernel, loss_head_kernel).  Here one workgroup owns a 16 x 16 output tile for all of K (its 8 waves split K
+// and are summed through LDS in wave order), so it can finish what depends on the complete sums: it stores the pre-activation
+// sums (slot 0 of the partial-sum buffer: nks = 1 for head_kernel / the env rider) and the tile's share of the head,
+// qpart[tile][row][a] = sum over its 16 units of relu(sum + bias) * W_q[unit][a] (slot A: the same with W_v, dueling).
+// fc1_bwd2_kernel adds the FC / 16 shares per row in its prologue: two launches and two round trips fewer per train step.
+// The activation rows go through LDS (each wave stages its own 16 x 200 slice with 16-byte coalesced loads: a fragment-shaped
+// global load would touch 64 cache lines per instruction); the weight columns are read directly (4 rows x 64 B per
+// instruction).  v_mfma_f32_16x16x4_f32, two accumulators (40-cycle dependent latency against a 32-cycle issue interval).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct FkArgs { Slices sl; const float *h3; float *hf; float *qpart; int FC, A, dueling, stot; NetOff off; };
+constexpr int FK_ROW = 204;                   // LDS row stride of a wave's 16 x 200 slice (floats): conflict-free ds_read_b64
+
+__global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
+    __shared__ float ast[8 * 16 * FK_ROW];
+    __shared__ float red[8 * 4 * 64];
+    const Slice s = a.sl.s[blockIdx.z];
+    const int M = s.count, m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int kw = wave * 200;                                           // this wave's K range
+    // weight column of this lane: k = kw + 50 g + t for MFMA t (lane group g supplies k index g of every step; A uses the same map)
+    const float *bcol = s.params + OFF_WF1 + (size_t)(kw + 50 * g) * a.FC + n0 + r;
+    float bv[50];
+#pragma unroll
+    for (int t = 0; t < 50; t++) bv[t] = bcol[(size_t)(FK_ABL == 2 ? 0 : t) * a.FC];
+    // stage the activation slice: 16 rows x 50 float4; rows past the slice are clamped (computed, never stored)
+    float *mine = ast + wave * 16 * FK_ROW;
+    float4 st[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int idx = lane + 64 * i, row = idx < 800 ? idx / 50 : 0, c4 = idx < 800 ? idx - row * 50 : 0;
+        const int mr = m0 + row < M ? m0 + row : M - 1;
+        st[i] = *reinterpret_cast<const float4 *>(a.h3 + (size_t)(s.s_off + mr) * 1600 + kw + 4 * (FK_ABL == 3 ? 0 : c4));
+    }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int idx = lane + 64 * i, row = idx / 50, c4 = idx - row * 50;
+        if (idx < 800) *reinterpret_cast<float4 *>(mine + row * FK_ROW + 4 * c4) = st[i];
+    }
+    __builtin_amdgcn_wave_barrier();                                     // the slice is this wave's own: no workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float *arow = mine + r * FK_ROW + 50 * g;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float2 av[25];                                                       // every LDS read goes out before the first MFMA: the chain
+#pragma unroll                                                           // must not wait for one read per step
+    for (int t = 0; t < 25; t++) av[t] = *reinterpret_cast<const float2 *>(arow + 2 * t);
+#pragma unroll
+    for (int t = 0; t < 25; t++) { keep(av[t].x); keep(av[t].y); }
+#pragma unroll
+    for (int t = 0; t < (FK_ABL == 1 ? 1 : 25); t++) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv[2 * t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv[2 * t + 1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[(wave * 4 + q) * 64 + lane] = acc0[q] + acc1[q];
+    __syncthreads();
+    if (threadIdx.x >= 256) return;
+    // thread (reg, lane) of the 16 x 16 tile: D[row = 4 (lane >> 4) + reg][col = lane & 15]; the 8 wave partials in wave order
+    const int reg = threadIdx.x >> 6, row = 4 * g + reg, col = r, mr = m0 + row, unit = n0 + col;
+    float v = red[reg * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 8; w++) v += red[(w * 4 + reg) * 64 + lane];
+    const bool live = mr < M;
+    const size_t srow = (size_t)s.s_off + (live ? mr : M - 1);
+    if (live) a.hf[srow * a.FC + unit] = v;                              // pre-activation sum (bias and relu belong to the consumer)
+    if (!a.qpart || FK_ABL == 4) return;
+    const float h = fmaxf(v + s.params[a.off.bf1 + unit], 0.f);
+    const int qs = a.A + 1;
+    float *qo = a.qpart + ((size_t)blockIdx.y * a.stot + srow) * qs;
+    for (int c = 0; c <= a.A; c++) {                                     // A columns of W_q (+ W_v for the dueling head)
+        if (c == a.A && !a.dueling) break;
+        float x = h * (c < a.A ? s.params[a.off.wq + unit * a.A + c] : s.params[a.off.wv + unit]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 16);       // over the tile's 16 units, fixed tree
+        if (col == 0 && live) qo[c] = x;
+    }
+}
+
+// Loss + head backward + fc1 backward in ONE launch.  Every workgroup first rebuilds the B targets from the qpart shares (cheap:
+// FC / 16 shares per Q value), i.e. what loss_head_kernel computed once and handed on through global memory; then the first n_dx
+// workgroups compute a 32 x 32 tile of dh3 (they need dhf of their 32 rows for all units: rebuilt from the fc1 sums into LDS), the
+// others eight 32 x 32 tiles of dW_fc1 in one 32-unit column block (dhf of all B rows for those 32 units).  The head's own
+// gradients (W_q, b_q, W_v, b_v, b_fc1) come from the first dW workgroup of every column block; loss / abs_err / y and the Adam
+// tick from workgroup 0.  Same arithmetic per element as loss_head_kernel + fc1_bwd_kernel.
+struct Bw1Args {
+    int algo, B, FC, A, dueling, stot, n_dx;
+    NetOff off;
+    const float *params, *pnext, *ptarget;   // online net; the nets slice 1 (s') and slice 2 (Double: s' again) went through
+    const float *hf, *qpart, *h3;
+    const uint8_t *act; const float *rew; const uint8_t *term; const float *isw;
+    double gamma;
+    float *grad, *dh3, *loss, *abs_err, *y_out;
+    AdamDev *adam; int tick;
+};
+constexpr int BW_DX_ROW = 4;                 // + floats of padding per dhf row in LDS (dX role): conflict-free ds_read_b128
+constexpr int BW_DW_ROW = 36;                // dhf row stride in LDS (dW role)
+
+// DX: the role is a template argument and the kernel branches ONCE, at the top, into one of two straight-line bodies (a role branch
+// around the pre-loads would put a vmcnt(0) join between them and the prologue's own loads)
+template <int AT, bool DX>
+__device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = L.B, FC = L.FC, A = AT == MAXA ? L.A : AT;
+    const float *P = L.params;
+    float (*dadv)[MAXA] = reinterpret_cast<float (*)[MAXA]>(smem);                  // [MAXTB][MAXA]
+    float *dv = smem + MAXTB * MAXA, *lterm = dv + MAXTB, *dadv2 = lterm + MAXTB, *big = dadv2 + 2 * MAXTB;     // big: role dependent
+    // (dadv2: the two-action plain head's dA as packed pairs [b][2], 16-byte aligned per two rows)
+    const bool lead = blockIdx.x == 0;
+    const bool dbl = L.algo == FB_ALGO_DOUBLE;
+    const int qs = A + 1, ntile = FC >> 4;
+    // ---- role of this workgroup, and EVERY global load its body needs, issued before the target computation: the fc1 sums, the
+    // unit parameters, the W_fc1 runs / h3 operands depend on nothing computed here, so the kernel makes one round trip to memory,
+    // not three (shares -> dhf inputs -> MFMA operands)
+    constexpr bool dx_role = DX;
+    const int mt = dx_role ? blockIdx.x / 50 : 0, t2 = dx_role ? 0 : blockIdx.x - L.n_dx, nt = t2 / 7, kg = t2 - nt * 7;
+    const int kt = dx_role ? blockIdx.x - mt * 50 : kg * 8 + wave;
+    auto unit_params = [&](int n, float &bias, float (&wq)[AT], float &wv) {
+        bias = P[L.off.bf1 + n];
+        wv = P[(L.dueling ? L.off.wv : L.off.bf1) + n];
+#pragma unroll
+        for (int c = 0; c < AT; c++) wq[c] = P[L.off.wq + n * A + (c < A ? c : 0)];
+    };
+    float pre_hf[32], pre_bias, pre_wq[AT], pre_wv, pre_a[16];
+    float4 pre_w[8];
+    if constexpr (DX) {
+        const int ch = FC < 512 ? FC : 512, n = tid < ch ? tid : 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) { const int bq_ = mt * 32 + q; pre_hf[q] = L.hf[(size_t)(bq_ < B ? bq_ : 0) * FC + n]; }
+        unit_params(n, pre_bias, pre_wq, pre_wv);
+        const int kh = ch / 16, nbeg = wave * (ch / 8) + (lane >> 5) * kh;
+        const float *brun = P + OFF_WF1 + (size_t)(kt * 32 + (lane & 31)) * FC + nbeg;
+#pragma unroll
+        for (int q = 0; q < 8; q++) pre_w[q] = *reinterpret_cast<const float4 *>(brun + (4 * q < kh ? 4 * q : 0));
+#pragma unroll
+        for (int q = 0; q < 16; q++) pre_a[q] = 0.f;
+    } else {
+        const int c = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const int b = (tid >> 5) + 16 * q; pre_hf[q] = L.hf[(size_t)(b < B ? b : 0) * FC + nt * 32 + c]; }
+#pragma unroll
+        for (int q = 2; q < 32; q++) pre_hf[q] = 0.f;
+        unit_params(nt * 32 + c, pre_bias, pre_wq, pre_wv);
+        const int ktc = kt < 50 ? kt : 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) { const int b = 2 * t + (lane >> 5); pre_a[t] = L.h3[(size_t)(b < B ? b : 0) * 1600 + ktc * 32 + (lane & 31)]; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) pre_w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- targets: thread (b = tid >> 4, j = tid & 15) adds the shares of tiles j, j + 16, .. ; 16-lane tree; lane j == 0 finishes
+    // No load under a branch and no load inside a loop of unknown trip count (hipcc waits vmcnt(0) at every such join: the first
+    // version of this prologue made ~10 dependent round trips): the head biases of the three nets and the shares of the first two
+    // tiles per lane (all of them for FC <= 512) are requested up front from clamped addresses and masked by selects.
+    float bqs[AT], bqn[AT], bq3[AT];
+#pragma unroll
+    for (int c = 0; c < AT; c++) { const int cc = c < A ? c : 0; bqs[c] = L.params[L.off.bq + cc]; bqn[c] = L.pnext[L.off.bq + cc]; bq3[c] = L.ptarget[L.off.bq + cc]; }
+    const int bvo = L.dueling ? L.off.bv : L.off.bq;
+    float bvs = L.params[bvo], bvn = L.pnext[bvo], bv3 = L.ptarget[bvo];
+    for (int b0 = 0; b0 < (BW_ABL == 1 ? 0 : B); b0 += 32) {
+        const int b = b0 + (tid >> 4), j = tid & 15, bc = b < B ? b : 0;
+        // the transition's reward / terminal / action ride with the shares
+        float rf = L.rew[bc], isw = L.isw ? L.isw[bc] : 1.f;
+        int termb = L.term[bc], a_b = L.act[bc];
+        float x0[2][AT + 1], x1[2][AT + 1], x2[2][AT + 1];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tile = j + 16 * u, tc = tile < ntile ? tile : 0;
+            const float *q0 = L.qpart + ((size_t)tc * L.stot + bc) * qs;
+#pragma unroll
+            for (int c = 0; c <= AT; c++) {
+                const int cc = c < qs ? c : 0;
+                x0[u][c] = q0[cc]; x1[u][c] = q0[(size_t)B * qs + cc]; x2[u][c] = q0[(size_t)(dbl ? 2 * B : 0) * qs + cc];
+            }
+        }
+        keep(rf); keep(isw); keep(termb); keep(a_b);
+        float qsv[AT + 1], qnv[AT + 1], q3v[AT + 1];
+#pragma unroll
+        for (int c = 0; c <= AT; c++) {
+            keep(x0[0][c]); keep(x1[0][c]); keep(x2[0][c]); keep(x0[1][c]); keep(x1[1][c]); keep(x2[1][c]);
+            const bool on = c < A || (c == A && L.dueling), on1 = on && j + 16 < ntile;
+            qsv[c] = (on ? x0[0][c] : 0.f) + (on1 ? x0[1][c] : 0.f);
+            qnv[c] = (on ? x1[0][c] : 0.f) + (on1 ? x1[1][c] : 0.f);
+            q3v[c] = (on ? x2[0][c] : 0.f) + (on1 ? x2[1][c] : 0.f);
+        }
+        for (int tile = j + 32; tile < ntile; tile += 16) {              // FC > 512 only
+            const float *q0 = L.qpart + ((size_t)tile * L.stot + bc) * qs;
+#pragma unroll
+            for (int c = 0; c <= AT; c++) {
+                const int cc = c < qs ? c : 0;
+                const bool on = c < A || (c == A && L.dueling);
+                const float y0 = q0[cc], y1 = q0[(size_t)B * qs + cc], y2 = q0[(size_t)(dbl ? 2 * B : 0) * qs + cc];
+                qsv[c] += on ? y0 : 0.f; qnv[c] += on ? y1 : 0.f; q3v[c] += on ? y2 : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c <= AT; c++)
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { qsv[c] += __shfl_xor(qsv[c], o, 16); qnv[c] += __shfl_xor(qnv[c], o, 16); q3v[c] += __shfl_xor(q3v[c], o, 16); }
+        // every lane finishes (no branch); only lane j == 0 of a live row publishes.  The V share sits in column A of the shares;
+        // with AT == MAXA that index is a run-time one: select it out
+        float vs = 0.f, vn = 0.f, v3 = 0.f;
+#pragma unroll
+        for (int c = 0; c <= AT; c++) { vs = c == A ? qsv[c] : vs; vn = c == A ? qnv[c] : vn; v3 = c == A ? q3v[c] : v3; }
+        // biases / dueling combine (BrainDuelingDQN.py:78-86) like head_one, with the head parameters of the net each slice went
+        // through: s -> online; s' -> online (DQN, Double's argmax) or target; Double's third slice -> target
+        auto fin = [&](float (&qv)[AT + 1], float vshare, const float (&bq)[AT], float bvv) {
+            float mean = 0.f;
+#pragma unroll
+            for (int c = 0; c < AT; c++) { qv[c] = c < A ? qv[c] + bq[c] : 0.f; mean += c < A ? qv[c] : 0.f; }
+            const float V = vshare + bvv;
+            mean /= (float)A;
+#pragma unroll
+            for (int c = 0; c < AT; c++) qv[c] = L.dueling ? V + (qv[c] - mean) : qv[c];
+        };
+        fin(qsv, vs, bqs, bvs);
+        fin(qnv, vn, bqn, bvn);
+        fin(q3v, v3, bq3, bv3);
+        float sel;
+        {
+            int am = 0;                                              // BrainDoubleDQN.py:51-54
+#pragma unroll
+            for (int c = 1; c < AT; c++) if (c < A && qnv[c] > qnv[am]) am = c;
+            float seld = q3v[0], selm = qnv[0];
+#pragma unroll
+            for (int c = 1; c < AT; c++) { seld = c == am ? q3v[c] : seld; selm = c < A ? fmaxf(selm, qnv[c]) : selm; }
+            sel = dbl ? seld : selm;
+        }
+        if (L.algo != FB_ALGO_PER) isw = 1.f;
+        // BrainDQN.py:210-215: python float64 arithmetic on the rewards 0.1 / 3 / -3, then fed as float32
+        const double rr = rf == 0.1f ? 0.1 : (double)rf;
+        const double yd = termb ? rr : rr + L.gamma * (double)sel;
+        const float y = (float)yd;
+        float qe = qsv[0];
+#pragma unroll
+        for (int c = 1; c < AT; c++) qe = c == a_b ? qsv[c] : qe;
+        const float d = y - qe;                                      // q_eval = reduce_sum(Q * onehot)
+        const float scale = L.algo == FB_ALGO_DQN ? 2.f : 2.f / (float)B;     // sum vs mean
+        const float gq = -scale * isw * d;                           // dLoss/dQ[b][a_b]
+        if (j == 0 && b < B) {
+            lterm[b] = isw * d * d;
+            if (lead && L.abs_err) L.abs_err[b] = fabsf(d);
+            if (lead && L.y_out) L.y_out[b] = y;
+            dv[b] = L.dueling ? gq : 0.f;
+#pragma unroll
+            for (int c = 0; c < AT; c++) dadv[b][c] = (c == a_b ? gq : 0.f) - (L.dueling ? gq / (float)A : 0.f);
+            if (AT == 2) { dadv2[2 * b] = dadv[b][0]; dadv2[2 * b + 1] = dadv[b][1]; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; q++) keep(pre_hf[q]);
+#pragma unroll
+    for (int q = 0; q < 16; q++) keep(pre_a[q]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { keep(pre_w[q].x); keep(pre_w[q].y); keep(pre_w[q].z); keep(pre_w[q].w); }
+    __syncthreads();
+    if (lead && tid == 0) {
+        float sum = 0.f;
+        for (int b = 0; b < B; b++) sum += lterm[b];
+        *L.loss = L.algo == FB_ALGO_DQN ? sum : sum / (float)B;
+        if (L.tick && L.adam->ticks == L.adam->applies) {            // Adam step counter for the update that follows (see AdamDev)
+            AdamDev &ad = *L.adam;
+            ad.alpha = ad.lr * sqrtf(1.f - ad.b2pow) / (1.f - ad.b1pow);
+            ad.b1pow *= ad.b1; ad.b2pow *= ad.b2;
+            ad.ticks += 1;
+        }
+    }
+    if (lead && tid >= 64 && tid < 64 + A) { const int c = tid - 64; float sum = 0.f; for (int b = 0; b < B; b++) sum += dadv[b][c]; L.grad[L.off.bq + c] = sum; }
+    if (lead && tid == 128 && L.dueling) { float sum = 0.f; for (int b = 0; b < B; b++) sum += dv[b]; L.grad[L.off.bv] = sum; }
+    // dhf[b][n] = relu'(fc1) * (dV * W_v[n] + sum_a dA[a] * W_q[n][a]) from a pre-loaded fc1 sum and the unit's parameters
+    auto dhf_of = [&](int b, float hfv, float bias, const float (&wq)[AT], float wv, float &hout) {
+        const float v = hfv + bias;
+        float d = L.dueling ? dv[b] * wv : 0.f;
+#pragma unroll
+        for (int c = 0; c < AT; c++) if (c < A) d = fmaf(dadv[b][c], wq[c], d);
+        hout = fmaxf(v, 0.f);
+        return v > 0.f ? d : 0.f;
+    };
+    const int hl = lane >> 5, i = lane & 31, jj = lane & 31;
+    if constexpr (DX) {
+        // ---- dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]: rows mt*32.., k tile kt; n in chunks of <= 512 units that the 8
+        // waves split (each lane half a run of ch / 16 units).  Thread n of a chunk rebuilds column n of dhf for the 32 rows.
+        const int RS = 512 + BW_DX_ROW;
+        float *dh = big, *red = big + 32 * RS;
+        f32x16 acc = {0};
+        for (int nc = 0; nc < FC; nc += 512) {
+            const int ch = FC - nc < 512 ? FC - nc : 512;
+            if (nc) {                                                // (FC > 512 only: later chunks load inside the loop)
+                __syncthreads();
+                const int n = nc + (tid < ch ? tid : 0);
+#pragma unroll
+                for (int q = 0; q < 32; q++) { const int bq_ = mt * 32 + q; pre_hf[q] = L.hf[(size_t)(bq_ < B ? bq_ : 0) * FC + n]; }
+                unit_params(n, pre_bias, pre_wq, pre_wv);
+                const int kh = ch / 16, nbeg = wave * (ch / 8) + hl * kh;
+                const float *brun = P + OFF_WF1 + (size_t)(kt * 32 + jj) * FC + nc + nbeg;
+#pragma unroll
+                for (int q = 0; q < 8; q++) pre_w[q] = *reinterpret_cast<const float4 *>(brun + (4 * q < kh ? 4 * q : 0));
+            }
+            if (tid < ch && BW_ABL != 2) {
+                if (AT == 2 && !L.dueling) {
+                    // two-action plain head: d = dA[b][0] * W_q[n][0] + dA[b][1] * W_q[n][1]; the 32 rows' (dA0, dA1) pairs arrive as 16
+                    // broadcast ds_read_b128, all in flight, instead of 64 dependent scalar reads
+                    float4 da[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) da[q] = *reinterpret_cast<const float4 *>(dadv2 + 2 * (mt * 32 + 2 * q < MAXTB - 1 ? mt * 32 + 2 * q : 0));
+                    float o[32];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const float v0 = pre_hf[2 * q] + pre_bias, v1 = pre_hf[2 * q + 1] + pre_bias;
+                        const float d0 = fmaf(da[q].y, pre_wq[1], fmaf(da[q].x, pre_wq[0], 0.f)), d1 = fmaf(da[q].w, pre_wq[1], fmaf(da[q].z, pre_wq[0], 0.f));
+                        o[2 * q] = (v0 > 0.f && mt * 32 + 2 * q < B) ? d0 : 0.f;
+                        o[2 * q + 1] = (v1 > 0.f && mt * 32 + 2 * q + 1 < B) ? d1 : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 32; q++) dh[q * RS + tid] = o[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 32; q++) {
+                        float hv;
+                        dh[q * RS + tid] = mt * 32 + q < B ? dhf_of(mt * 32 + q, pre_hf[q], pre_bias, pre_wq, pre_wv, hv) : 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+            const int kh = ch / 16, nbeg = wave * (ch / 8) + hl * kh;
+            const float *arun = dh + i * RS + nbeg;
+            float4 xa[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) xa[q] = *reinterpret_cast<const float4 *>(arun + (4 * q < kh ? 4 * q : 0));
+#pragma unroll
+            for (int q = 0; q < 8; q++) { keep(xa[q].x); keep(xa[q].y); keep(xa[q].z); keep(xa[q].w); }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (4 * q < kh && BW_ABL != 3) {
+                    const float4 x = xa[q], w = pre_w[q];
+                    acc = mfma(x.x, w.x, acc); acc = mfma(x.y, w.y, acc); acc = mfma(x.z, w.z, acc); acc = mfma(x.w, w.w, acc);
+                }
+            }
+        }
+        reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
+            const size_t o = (size_t)mr * 1600 + kt * 32 + jj;
+            L.dh3[o] = BW_ABL == 4 ? v : (L.h3[o] > 0.f ? v : 0.f);
+        });
+        return;
+    }
+    if (BW_ABL == 5) return;
+    // ---- dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: column block nt (32 units), k tiles kg*8 + wave; + the head's gradients
+    float *dh = big, *hh = big + MAXTB * BW_DW_ROW;                       // dhf and relu(fc1) of all B rows, 32 units
+    {
+        const int c = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int b = (tid >> 5) + 16 * q;
+            if (b < B) { float hv; dh[b * BW_DW_ROW + c] = dhf_of(b, pre_hf[q], pre_bias, pre_wq, pre_wv, hv); hh[b * BW_DW_ROW + c] = hv; }
+        }
+        for (int b = (tid >> 5) + 32; b < B; b += 16) {                 // B > 32: the rest of the rows (loads inside the loop)
+            float hv;
+            dh[b * BW_DW_ROW + c] = dhf_of(b, L.hf[(size_t)b * FC + nt * 32 + c], pre_bias, pre_wq, pre_wv, hv);
+            hh[b * BW_DW_ROW + c] = hv;
+        }
+    }
+    __syncthreads();
+    if (kt < 50) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int t = 0; t < 16; t++) {                                   // samples 0..31: A operands pre-loaded at the top
+            const int b = 2 * t + hl;
+            const float w = dh[(b < B ? b : 0) * BW_DW_ROW + jj];
+            acc = mfma(b < B ? pre_a[t] : 0.f, b < B ? w : 0.f, acc);
+        }
+#pragma unroll 4
+        for (int t = 16; t < (B + 1) / 2; t++) {
+            const int b = 2 * t + hl, bc = b < B ? b : 0;
+            const float x = L.h3[(size_t)bc * 1600 + kt * 32 + i], w = dh[bc * BW_DW_ROW + jj];
+            acc = mfma(b < B ? x : 0.f, b < B ? w : 0.f, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) L.grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + jj] = acc[r];
+    }
+    if (kg != 0) return;
+    // head gradients of units nt*32 .. +32: thread (c = tid & 31, part = tid >> 5) sums b = part, part + 16, ..; 16 parts in order
+    float *part = hh + MAXTB * BW_DW_ROW;                                 // [16][32][AT + 2]
+    {
+        const int c = tid & 31, pt = tid >> 5;
+        float gw[AT], gv = 0.f, gb = 0.f;
+#pragma unroll
+        for (int q = 0; q < AT; q++) gw[q] = 0.f;
+        for (int b = pt; b < B; b += 16) {
+            const float h = hh[b * BW_DW_ROW + c];
+#pragma unroll
+            for (int q = 0; q < AT; q++) if (q < A) gw[q] = fmaf(h, dadv[b][q], gw[q]);
+            gv = fmaf(h, dv[b], gv);
+            gb += dh[b * BW_DW_ROW + c];
+        }
+        float *po = part + (pt * 32 + c) * (AT + 2);
+#pragma unroll
+        for (int q = 0; q < AT; q++) po[q] = gw[q];
+        po[AT] = gv; po[AT + 1] = gb;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int n = nt * 32 + tid;
+        float acc[AT + 2];
+#pragma unroll
+        for (int q = 0; q < AT + 2; q++) acc[q] = part[tid * (AT + 2) + q];
+        for (int pt = 1; pt < 16; pt++)
+#pragma unroll
+            for (int q = 0; q < AT + 2; q++) acc[q] += part[(pt * 32 + tid) * (AT + 2) + q];
+#pragma unroll
+        for (int q = 0; q < AT; q++) if (q < A) L.grad[L.off.wq + n * A + q] = acc[q];
+        if (L.dueling) L.grad[L.off.wv + n] = acc[AT];
+        L.grad[L.off.bf1 + n] = acc[AT + 1];
+    }
+}
+
+constexpr int BW_LDS_COMMON = MAXTB * MAXA + 4 * MAXTB;
+constexpr int BW_LDS_DX = 32 * (512 + BW_DX_ROW) + 8 * 16 * 64, BW_LDS_DW = 2 * MAXTB * BW_DW_ROW + 16 * 32 * (MAXA + 2);
+constexpr int BW_LDS = BW_LDS_COMMON + (BW_LDS_DX > BW_LDS_DW ? BW_LDS_DX : BW_LDS_DW);        // 27 264 floats = 109 KB
+
+__global__ __launch_bounds__(512) void fc1_bwd2_kernel(Bw1Args L) {
+    __shared__ float smem_bw[BW_LDS];
+    const bool dx = (int)blockIdx.x < L.n_dx;
+    if (L.A == 2) { if (dx) fc1_bwd2_body<2, true>(L, smem_bw); else fc1_bwd2_body<2, false>(L, smem_bw); }
+    else { if (dx) fc1_bwd2_body<MAXA, true>(L, smem_bw); else fc1_bwd2_body<MAXA, false>(L, smem_bw); }
+}
+
 // ================================================================== backward
 // dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
 __device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h3, const float *__restrict__ dhf,
@@ -1485,6 +1919,7 @@ struct fb_qnet {
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
+    float *qpart;                    // small-batch training: per 16-unit tile shares of the head, [FC/16][S][A + 1]
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
     int zmax;
@@ -1528,6 +1963,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
     alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
+    alloc((void **)&h->qpart, (size_t)(fc_width / 16) * S * (MAXA + 1) * 4);
     const size_t Bm = max_batch;
     alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
     alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
@@ -1548,7 +1984,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
     void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->slabs1, h->adam, h->p1, h->amax, h->h2,
-                    h->h3, h->hf, h->q, h->dhf, h->dh3, h->dh2, h->dp1};
+                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return FB_OK;
@@ -1700,15 +2136,23 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (big) hipLaunchKernelGGL(conv3_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->h2, h->h3);
         else hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
     }
-    if (!sp) FB_K(K_FC1) {
+    // small batches: the whole K per workgroup (fc1_fk_kernel), which lets training skip the head and loss launches
+    const bool fk = !sp && !big;
+    if (fk) FB_K(K_FC1) {
+        FkArgs fa;
+        fa.sl = p.sl; fa.h3 = h->h3; fa.hf = h->hf; fa.qpart = p.train ? h->qpart : nullptr; fa.FC = h->FC; fa.A = h->A;
+        fa.dueling = h->arch == FB_ARCH_DUELING; fa.stot = stot; fa.off = h->off;
+        hipLaunchKernelGGL(fc1_fk_kernel, dim3((maxc + 15) / 16, h->FC / 16, p.ns), dim3(512), 0, st, fa);
+    }
+    if (!sp && !fk) FB_K(K_FC1) {
         if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_BIG_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
         else hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
     }
-    FB_K(K_HEAD) {
+    if (!(fk && p.train)) FB_K(K_HEAD) {            // (small-batch training gets Q from fc1_fk_kernel's shares instead)
         HeadArgs H;
         H.sl = p.sl; H.nslices = p.ns;
         HeadCore &C = H.c;
-        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : FC1_KS; C.q = h->q; C.FC = h->FC; C.A = h->A;
+        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : 1; C.q = h->q; C.FC = h->FC; C.A = h->A;
         C.dueling = h->arch == FB_ARCH_DUELING; C.off = h->off; C.actions = p.actions; C.epsilon = p.epsilon;
         C.seed_lo = (uint32_t)p.seed; C.seed_hi = (uint32_t)(p.seed >> 32);
         C.step_lo = (uint32_t)p.step; C.step_hi = (uint32_t)(p.step >> 32);
@@ -1718,7 +2162,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     if (p.train) {
         const int B = p.B, FC = h->FC;
         float *G = p.G;
-        FB_K(K_LOSS) {
+        if (!fk) FB_K(K_LOSS) {
             LossArgs L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
             L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = big ? FC1_BIG_KS : FC1_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
@@ -1737,7 +2181,16 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         const int z2 = z3;
         const size_t ss = CONV_PARAMS;
         const int ndx1 = ((B + 31) / 32) * 50, ndw1 = (50 * (FC / 32) + 7) / 8;
-        FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+        if (fk) { FB_K(K_FC1_BWD) {
+            Bw1Args L;
+            L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.stot = stot; L.n_dx = ndx1; L.off = h->off;
+            L.params = h->params[0]; L.pnext = p.sl.s[1].params; L.ptarget = p.ns > 2 ? p.sl.s[2].params : p.sl.s[1].params;
+            L.hf = h->hf; L.qpart = h->qpart; L.h3 = h->h3; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw; L.gamma = p.gamma;
+            L.grad = G; L.dh3 = h->dh3; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
+            if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
+            L.adam = h->adam; L.tick = p.tick;
+            hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7), dim3(512), 0, st, L);
+        } } else FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
         const int ndx3 = ((B * 25 + 31) / 32) * 2;
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
