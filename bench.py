@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 N_ENVS, BATCH, CAPACITY = 1024, 32, 1_000_000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense (the F16 forms take the same cycles)
 
 # algorithmic flops / bytes per launch (n = samples in the launch)
 FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64 * 512,
@@ -206,23 +206,24 @@ def main():
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
 
         def add(name, us, per_step, bound, work, split=0):
-            # split = s > 0: the kernel computes fp32 products as s bf16 x bf16 MFMA products:
-            # conv1 3 (u8 input is exact in bf16), the split-bf16 acting kernels 6; priced against the bf16 dense peak.
-            split = split or (3 if name.startswith("conv1_pool_kernel") else 0)
+            # split = s > 0: the kernel computes every fp32 product as s fp16 x fp16 MFMA products of two-plane operands
+            # (DESIGN.md section 4): conv1 2 (its u8 input is exact in fp16), the acting conv2/conv3/fc1 kernels 3; priced
+            # against the dense fp16 MFMA peak (= the bf16 one).
+            split = split or (2 if name.startswith("conv1_pool_kernel") else 0)
             peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF)
             ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
             k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
                  "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                  "frac": round(ach / peak, 5), "traffic": pmc.get(name)}
             if split:
-                # the kernel's algorithm IS `split` bf16 products per fp32 product: achieved = the bf16 flops it
+                # the kernel's algorithm IS `split` fp16 products per fp32 product: achieved = the fp16 flops it
                 # performs (all of them necessary), beside the fp32-equivalent rate they amount to
-                k["dtype"] = f"bf16x{split} (fp32 result)"
+                k["dtype"] = f"f16x{split} (fp32 result)"
                 k["fp32_equivalent_tflops"] = k["achieved"]
                 k["achieved"] = round(split * ach, 3)
                 k["frac"] = round(split * ach / peak, 5)
-                k["note"] = ("peak = nominal dense bf16; tools/mb/mb_mfma3.hip measures 1.47 PFLOP/s sustained on random "
-                             "operands with all CUs busy (power throttling), 2.3 PFLOP/s on zeros")
+                k["note"] = ("peak = nominal dense fp16/bf16 MFMA; tools/mb/mb_mfma3.hip measures 1.47 PFLOP/s sustained on "
+                             "random operands with all CUs busy (power throttling), 2.3 PFLOP/s on zeros")
             kernels.append(k)
 
         scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
@@ -238,9 +239,9 @@ def main():
         # acting forward, n = 1024
         scratch.act_nib(nib, 0.0)
         # (>= 256 states, forward only: the split-bf16 kernels; conv3 rides in conv2's launch)
-        act = [(0, "conv1_sp_kernel<nib>", FWD_FLOP["conv1_pool_kernel"], 3),
-               (1, "conv23_sp_kernel", FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"], 6),
-               (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 6), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]
+        act = [(0, "conv1_sp_kernel<nib>", FWD_FLOP["conv1_pool_kernel"], 2),
+               (1, "conv23_sp_kernel", FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"], 3),
+               (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 3), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]
         for k, name, flop, split in act:
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
                                                                   None, None, st()), "profile"), R)

@@ -213,15 +213,42 @@ __device__ __forceinline__ void split3x2(float x0, float x1, uint32_t &hi, uint3
     hi = __builtin_bit_cast(uint32_t, h); mid = __builtin_bit_cast(uint32_t, m); lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// ---- fp32 as TWO fp16 numbers.  x = h + l / 4096 with h = fp16(x) and l = fp16((x - h) * 4096), both rounded to nearest:
+// |x - h| <= 2^-12 |x| and the second rounding leaves 2^-12 of that, so the pair carries x to 2^-24 relative -- fp32's own
+// precision (2 x 11 significand bits plus the two roundings' sign bits); the scale keeps l in h's exponent range instead of
+// fp16's subnormals.  A product a * w is then ah*wh + (ah*wl + al*wh) / 4096 + (al*wl) / 2^24: every fp16 x fp16 product is
+// exact in the MFMA's fp32 accumulator, the last term is below one fp32 rounding and is dropped.  THREE v_mfma_f32_32x32x16_f16
+// per 16 k (one into the main accumulator, two into a second one that is folded in with an exact power-of-two scale at the end)
+// replace the SIX bf16 products of the hi/mid/lo split this path used before (three bf16 planes, 8 bits each) at the same
+// accuracy: half the matrix cycles, two operand planes instead of three.  (Range: |x| must stay below 65504, fp16's maximum;
+// the reference network's activations are O(1..100).)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO_SCALE = 4096.f, F16_LO_UNSCALE = 1.f / 4096.f;
+__device__ __forceinline__ void split2x2(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+    const f32x2 x = {x0, x1};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * F16_LO_SCALE;
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(uint32_t, h); lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ f32x16 mfma_h(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_b(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+constexpr uint32_t F16_255 = 0x5BF8u;        // 255.0 as fp16 (a lit pixel)
+
+// W_conv1 in that form: w1s[part][ky][kq][h][co][8] fp16, part 0 = h, part 1 = l (conv1's u8 input is exact in fp16, so conv1 needs
+// only x*wh and x*wl: two MFMAs per 16 k)
 __device__ __forceinline__ void split_w1(const float w, int idx /* flat index in W_conv1[8][8][4][32] */, uint16_t *__restrict__ w1s) {
     const int co = idx & 31, f = (idx >> 5) & 3, kx = (idx >> 7) & 7, ky = idx >> 10;
     const int kq = kx >> 2, h = (kx >> 1) & 1, j = (kx & 1) * 4 + f;
-    const uint32_t hi = f32_to_bf16_rn(w);
-    const float r1 = w - __uint_as_float(hi << 16);
-    const uint32_t mid = f32_to_bf16_rn(r1);
-    const uint32_t lo = f32_to_bf16_rn(r1 - __uint_as_float(mid << 16));
+    const _Float16 hh = (_Float16)w;
+    const _Float16 ll = (_Float16)((w - (float)hh) * F16_LO_SCALE);
     const size_t o = ((((size_t)ky * 2 + kq) * 2 + h) * 32 + co) * 8 + j;
-    w1s[o] = (uint16_t)hi; w1s[8192 + o] = (uint16_t)mid; w1s[16384 + o] = (uint16_t)lo;
+    w1s[o] = __builtin_bit_cast(uint16_t, hh); w1s[8192 + o] = __builtin_bit_cast(uint16_t, ll);
 }
 
 // (runs whenever the host replaced a net's parameters: it also bumps that net's parameter version, see AdamDev)
@@ -231,16 +258,22 @@ __global__ void w1_split_kernel(const float *__restrict__ params, uint16_t *__re
     if (idx == 0 && pver) *pver += 1;
 }
 
-__device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
+// 8 bytes -> 8 fp16 (exact: every u8 value has <= 8 significant bits)
+__device__ __forceinline__ uint4 u8x8_to_f16(uint2 v) {
     uint4 o;
-    const float f0 = (float)(v.x & 255u), f1 = (float)((v.x >> 8) & 255u), f2 = (float)((v.x >> 16) & 255u), f3 = (float)(v.x >> 24);
-    const float f4 = (float)(v.y & 255u), f5 = (float)((v.y >> 8) & 255u), f6 = (float)((v.y >> 16) & 255u), f7 = (float)(v.y >> 24);
-    // upper halves of two floats -> one dword (exact: <= 8 significant bits)
-    o.x = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
-    o.y = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
-    o.z = __builtin_amdgcn_perm(__float_as_uint(f5), __float_as_uint(f4), 0x07060302u);
-    o.w = __builtin_amdgcn_perm(__float_as_uint(f7), __float_as_uint(f6), 0x07060302u);
-    return __builtin_bit_cast(bf16x8, o);
+    const f32x2 p0 = {(float)(v.x & 255u), (float)((v.x >> 8) & 255u)}, p1 = {(float)((v.x >> 16) & 255u), (float)(v.x >> 24)};
+    const f32x2 p2 = {(float)(v.y & 255u), (float)((v.y >> 8) & 255u)}, p3 = {(float)((v.y >> 16) & 255u), (float)(v.y >> 24)};
+    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, f16x2)); o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, f16x2));
+    o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, f16x2)); o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, f16x2));
+    return o;
+}
+__device__ __forceinline__ uint4 nib_lut_entry(unsigned t) {   // byte t = 2 pixels x 4 frames (bit 4*px + f) -> the 8 k-values of one lane
+    uint4 e;
+    e.x = ((t >> 0) & 1u) * F16_255 | ((t >> 1) & 1u) * (F16_255 << 16);
+    e.y = ((t >> 2) & 1u) * F16_255 | ((t >> 3) & 1u) * (F16_255 << 16);
+    e.z = ((t >> 4) & 1u) * F16_255 | ((t >> 5) & 1u) * (F16_255 << 16);
+    e.w = ((t >> 6) & 1u) * F16_255 | ((t >> 7) & 1u) * (F16_255 << 16);
+    return e;
 }
 
 // conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2; one wave per tile of 8 pooled pixels x 4
@@ -254,13 +287,7 @@ template <bool NIB>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
     __shared__ uint4 lut[NIB ? 256 : 1];
     if (NIB) {
-        const unsigned t = threadIdx.x;                       // element j = 4*px + f  <->  bit j of the byte; 255.0 = 0x437F
-        uint4 e;
-        e.x = ((t >> 0) & 1u) * 0x437Fu | ((t >> 1) & 1u) * 0x437F0000u;
-        e.y = ((t >> 2) & 1u) * 0x437Fu | ((t >> 3) & 1u) * 0x437F0000u;
-        e.z = ((t >> 4) & 1u) * 0x437Fu | ((t >> 5) & 1u) * 0x437F0000u;
-        e.w = ((t >> 6) & 1u) * 0x437Fu | ((t >> 7) & 1u) * 0x437F0000u;
-        lut[t] = e;
+        lut[threadIdx.x] = nib_lut_entry(threadIdx.x);       // element j = 4*px + f  <->  bit j of the byte
         __syncthreads();
     }
     const Slice s = sl.s[blockIdx.z];
@@ -271,7 +298,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
     const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
     const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
     const uint4 *WB = reinterpret_cast<const uint4 *>(s.w1s) + hl * 32 + j;      // [part][ky][kq][h][co] x 16 B
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acl = {0};
 #pragma unroll 2
     for (int ky = 0; ky < 8; ky++) {
         const int iy = oy * 4 + ky - 2;
@@ -282,23 +309,22 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
         for (int kq = 0; kq < 2; kq++) {
             const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;         // even: the pixel pair is inside or outside together
             const bool ok = rowok && ix >= 0 && ix < 80;
-            bf16x8 A;
+            uint4 A;
             const int ixc = ok ? ix : 0;                         // a valid address for the padding taps too; zeroed by a select
             if (NIB) {
                 const unsigned idx = row[ixc >> 1];
-                A = __builtin_bit_cast(bf16x8, lut[ok ? idx : 0u]);      // entry 0 = all zero = the SAME padding
+                A = lut[ok ? idx : 0u];                          // entry 0 = all zero = the SAME padding
             } else {
                 const uint2 v = *reinterpret_cast<const uint2 *>(row + (size_t)ixc * 4);
-                A = u8x8_to_bf16(make_uint2(ok ? v.x : 0u, ok ? v.y : 0u));
+                A = u8x8_to_f16(make_uint2(ok ? v.x : 0u, ok ? v.y : 0u));
             }
-#pragma unroll
-            for (int part = 0; part < 3; part++) {
-                const uint4 wv = WB[((part * 8 + ky) * 2 + kq) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, wv), acc, 0, 0, 0);
-            }
+            acc = mfma_h(A, WB[((0 * 8 + ky) * 2 + kq) * 64], acc);
+            acl = mfma_h(A, WB[((1 * 8 + ky) * 2 + kq) * 64], acl);
         }
     }
     const float bias = s.params[OFF_B1 + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);      // x*wh + (x*wl) / 4096: exact scale, one rounding
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         float bv = fmaxf(acc[4 * g] + bias, 0.f);
@@ -465,14 +491,18 @@ __device__ __forceinline__ void wsplit_item(const float *__restrict__ params, ui
     else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
     else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
     const int k8 = id / N, col = id - k8 * N;
-    uint32_t hi[4], mid[4], lo[4];
+    // plane 0: fp16 h, plane 1: fp16 l (split2x2), plane 2: the weight rounded to bf16 (bf16 inference mode, FB_DTYPE_BF16)
+    uint32_t hi[4], lo[4], bh[4], m_, l_;
 #pragma unroll
-    for (int e = 0; e < 4; e++)
-        split3x2(W[(size_t)(k8 * 8 + 2 * e) * N + col], W[(size_t)(k8 * 8 + 2 * e + 1) * N + col], hi[e], mid[e], lo[e]);
+    for (int e = 0; e < 4; e++) {
+        const float w0 = W[(size_t)(k8 * 8 + 2 * e) * N + col], w1 = W[(size_t)(k8 * 8 + 2 * e + 1) * N + col];
+        split2x2(w0, w1, hi[e], lo[e]);
+        split3x2(w0, w1, bh[e], m_, l_);
+    }
     uint4 *o = out + (size_t)k8 * 3 * N + col;
     o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    o[N] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
-    o[2 * N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    o[N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    o[2 * N] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
 }
 
 // stand-alone re-split (the acting forward normally does it inside its conv1 launch): only when the versions differ
@@ -512,11 +542,11 @@ template <bool NIB>
 __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
                                                                   size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC,
                                                                   const unsigned *__restrict__ pver, const unsigned *__restrict__ wver) {
-    __shared__ uint4 wl[3 * 16 * 64];
+    __shared__ uint4 wl[2 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
     const int bid = blockIdx.x, nblk = gridDim.x;
     // this workgroup's weight copy goes out first, the re-split items' loads right behind it (one round trip, not two)
-    constexpr int WQ = 3 * 16 * 64, WC = (WQ + 64 * C1_WAVES - 1) / (64 * C1_WAVES);
+    constexpr int WQ = 2 * 16 * 64, WC = (WQ + 64 * C1_WAVES - 1) / (64 * C1_WAVES);
     uint4 wcopy[WC];
 #pragma unroll
     for (int u = 0; u < WC; u++) { const int q = threadIdx.x + u * 64 * C1_WAVES; wcopy[u] = reinterpret_cast<const uint4 *>(s.w1s)[q < WQ ? q : 0]; }
@@ -528,15 +558,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
     }
 #pragma unroll
     for (int u = 0; u < WC; u++) { const int q = threadIdx.x + u * 64 * C1_WAVES; if (q < WQ) wl[q] = wcopy[u]; }
-    if (NIB && threadIdx.x < 256) {
-        const unsigned t = threadIdx.x;
-        uint4 e;
-        e.x = ((t >> 0) & 1u) * 0x437Fu | ((t >> 1) & 1u) * 0x437F0000u;
-        e.y = ((t >> 2) & 1u) * 0x437Fu | ((t >> 3) & 1u) * 0x437F0000u;
-        e.z = ((t >> 4) & 1u) * 0x437Fu | ((t >> 5) & 1u) * 0x437F0000u;
-        e.w = ((t >> 6) & 1u) * 0x437Fu | ((t >> 7) & 1u) * 0x437F0000u;
-        lut[t] = e;
-    }
+    if (NIB && threadIdx.x < 256) lut[threadIdx.x] = nib_lut_entry(threadIdx.x);
     __syncthreads();
     typedef typename std::conditional<NIB, unsigned, uint2>::type Raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31, pp = j >> 2, pos = j & 3;
@@ -580,16 +602,17 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
         int z;                                   // opaque 0: keeps the 48 weight fragments in LDS (re-read per tile)
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));      // instead of hoisted into 192 registers at one wave per SIMD
         const uint4 *wlz = wl + z;
-        f32x16 acc = {0};
+        f32x16 acc = {0}, acl = {0};
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            bf16x8 A;
-            if constexpr (NIB) A = __builtin_bit_cast(bf16x8, lut[cur[c]]);
-            else A = u8x8_to_bf16(cur[c]);
-#pragma unroll
-            for (int part = 0; part < 3; part++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, wlz[(part * 16 + c) * 64 + lane]), acc, 0, 0, 0);
+            uint4 A;
+            if constexpr (NIB) A = lut[cur[c]];
+            else A = u8x8_to_f16(cur[c]);
+            acc = mfma_h(A, wlz[(0 * 16 + c) * 64 + lane], acc);
+            acl = mfma_h(A, wlz[(1 * 16 + c) * 64 + lane], acl);
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);
         // D[row = 4 * pixel + window position][col = channel]: register r of a lane is window position r & 3 of pooled pixel
         // 2 * (r >> 2) + hl for channel j, so the 2x2 max-pool is a max over 4 registers; relu(max + bias) (monotone, so equal
         // to the max of the relu'd values).  The quad transpose then gives lane l of quad q pixel 2 * l + hl, channels 4q..4q+3.
@@ -598,16 +621,13 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
         for (int g = 0; g < 4; g++) o4[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias, 0.f);
         quad_transpose(o4, j & 3);
         const int Pp = tile * 8 + 2 * (j & 3) + hl;
-        uint32_t hi[2], mid[2], lo[2];
-        split3x2(o4[0], o4[1], hi[0], mid[0], lo[0]);
-        split3x2(o4[2], o4[3], hi[1], mid[1], lo[1]);
+        uint32_t hi[2], lo[2], m_, l_;
+        if (nsplit == 3) { split2x2(o4[0], o4[1], hi[0], lo[0]); split2x2(o4[2], o4[3], hi[1], lo[1]); }      // fp16 h / l planes
+        else { split3x2(o4[0], o4[1], hi[0], m_, l_); split3x2(o4[2], o4[3], hi[1], m_, l_); lo[0] = lo[1] = 0u; }     // one bf16 plane
         if (Pp < npool) {
             uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 4 * (j >> 2);
             *reinterpret_cast<uint2 *>(o) = make_uint2(hi[0], hi[1]);
-            if (nsplit == 3) {
-                *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(mid[0], mid[1]);
-                *reinterpret_cast<uint2 *>(o + 2 * p1plane) = make_uint2(lo[0], lo[1]);
-            }
+            if (nsplit == 3) *reinterpret_cast<uint2 *>(o + p1plane) = make_uint2(lo[0], lo[1]);
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) cur[q] = nxt[q];
@@ -642,7 +662,9 @@ struct C23Args {
 #endif
 template <int NS>
 __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
-    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NS * IN_P, RING = ZOFF + 16, RSZ = 4 * NS * 64;   // uint4 units
+    // NS = 3: fp32-equivalent arithmetic on two fp16 planes (h, l; three products per step); NS = 1: one bf16 plane
+    constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;             // operand planes in use / first weight plane of wsp
+    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NPL * IN_P, RING = ZOFF + 16, RSZ = 4 * NPL * 64;   // uint4 units
     __shared__ uint4 smem[RING + 3 * RSZ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
     const int s0 = blockIdx.x * 5, ml = wave * 32 + j;
@@ -651,27 +673,27 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     const bool rowok = ml < 125;
     int nloc = a.n - s0; if (nloc > 5) nloc = 5;
     // weight staging registers: named members, no arrays (hipcc otherwise parks them in LDS / scratch)
-    struct BSt { uint4 v0, v1, v2; };
+    struct BSt { uint4 v0, v1; };
     auto srcB = [&](int cc, int q) {
-        const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;
-        return a.w + (size_t)cc * 768 + (k8 * 3 + pl) * 64 + lane;
+        const int e = wave + 4 * q, k8 = e / NPL, pl = e - k8 * NPL;
+        return a.w + (size_t)cc * 768 + (k8 * 3 + P0 + pl) * 64 + lane;
     };
     auto loadB = [&](int cc) {               // by value throughout: a reference into a lambda defeats SROA (staging lands in LDS)
         BSt r;
         r.v0 = *srcB(cc, 0);
-        if (NS == 3) { r.v1 = *srcB(cc, 1); r.v2 = *srcB(cc, 2); } else { r.v1 = r.v0; r.v2 = r.v0; }
+        if (NPL == 2) r.v1 = *srcB(cc, 1); else r.v1 = r.v0;
         return r;
     };
     auto storeB = [&](int slot, const BSt r) {
         uint4 *d = smem + RING + slot * RSZ + wave * 64 + lane;
         d[0] = r.v0;
-        if (NS == 3) { d[256] = r.v1; d[512] = r.v2; }
+        if (NPL == 2) d[256] = r.v1;
     };
     BSt bstA = loadB(0), bstB = loadB(1);
     {   // the five input images, plane by plane; piece q of pixel pix lands on piece (q + (pix >> 2)) & 3
-        uint4 t[NS][8];
+        uint4 t[NPL][8];
 #pragma unroll
-        for (int p = 0; p < NS; p++)
+        for (int p = 0; p < NPL; p++)
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int q = threadIdx.x + 256 * r;
@@ -680,7 +702,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
                 if (ok) t[p][r] = reinterpret_cast<const uint4 *>(a.p1s + p * a.pl1 + (size_t)s0 * 3200)[q];
             }
 #pragma unroll
-        for (int p = 0; p < NS; p++)
+        for (int p = 0; p < NPL; p++)
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int q = threadIdx.x + 256 * r, pix = q >> 2;
@@ -692,24 +714,25 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     // cc run on fragments already in registers, the fragments of chunk cc + 1 are read from LDS into a second
     // register set, the staged weights of chunk cc + 2 go into ring slot (cc + 2) % 3 and the global loads of chunk
     // cc + 4 are issued; one barrier per chunk.
-    struct Fr { uint4 A[2][NS]; uint4 W[2][2][NS]; };
+    struct Fr { uint4 A[2][NPL]; uint4 W[2][2][NPL]; };
     auto readW = [&](int cc, Fr f) {
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-                for (int p = 0; p < NS; p++) f.W[s][ct][p] = smem[RING + (cc % 3) * RSZ + ((2 * s + hl) * NS + p) * 64 + ct * 32 + j];
+                for (int p = 0; p < NPL; p++) f.W[s][ct][p] = smem[RING + (cc % 3) * RSZ + ((2 * s + hl) * NPL + p) * 64 + ct * 32 + j];
         return f;
     };
     auto readA = [&](auto aidx, Fr f) {          // aidx(s, p) -> LDS index of this lane's activation fragment
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
-            for (int p = 0; p < NS; p++) f.A[s][p] = smem[aidx(s, p)];
+            for (int p = 0; p < NPL; p++) f.A[s][p] = smem[aidx(s, p)];
         return f;
     };
-    f32x16 acc[2] = {{0}, {0}};
+    // acc: the h*h products; acl: h*l + l*h, folded in with the exact factor 1 / 4096 in the epilogue (NS = 3 only)
+    f32x16 acc[2] = {{0}, {0}}, acl[2] = {{0}, {0}};
     auto compute = [&](const Fr f) {
         // NB the MFMA intrinsics are pure: nothing but a data dependence orders them.  Without the ordered use of the
         // accumulators at the head of each FB_STEP hipcc hoists them across the barrier to right behind the LDS reads that
@@ -718,14 +741,11 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
-#ifdef C23_NO_MFMA
-#define FB_M(pa, pb) acc[ct][0] += __builtin_bit_cast(float, f.W[s][ct][pb].x ^ f.A[s][pa].x)
-#else
-#define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.W[s][ct][pb]), __builtin_bit_cast(bf16x8, f.A[s][pa]), acc[ct], 0, 0, 0)
-#endif
-                if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }      // small terms first
-                FB_M(0, 0);
-#undef FB_M
+                if constexpr (NS == 3) {
+                    acl[ct] = mfma_h(f.W[s][ct][0], f.A[s][1], acl[ct]);
+                    acl[ct] = mfma_h(f.W[s][ct][1], f.A[s][0], acl[ct]);
+                    acc[ct] = mfma_h(f.W[s][ct][0], f.A[s][0], acc[ct]);
+                } else acc[ct] = mfma_b(f.W[s][ct][0], f.A[s][0], acc[ct]);
             }
     };
     auto a2 = [&](int c) {                       // conv2 chunk c = tap (ky, kx), 32 channels
@@ -749,16 +769,17 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #define FB_STEP(cc, ST, AIDX_NEXT, HAVE_A)                                                                        \
     {                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));     /* see compute(): chunk cc's MFMAs stay behind chunk cc - 1's barrier */ \
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acl[0]), "+a"(acl[1]));     /* see compute(): chunk cc's MFMAs stay behind chunk cc - 1's barrier */ \
         Fr nx = cur;                                                                                                   \
         if ((cc) + 1 < 34 && !C23_NO_LDSR) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }        \
         compute(cur);                                                                                                  \
         if ((cc) + 2 < 34 && !C23_NO_W) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); }       \
         /* issue order inside the chunk: one LDS read / ring write / global load behind each MFMA, so that the LDS pipe   \
            and the MFMA pipe run side by side instead of in two phases that the per-chunk barrier keeps in lock step */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 18; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-        _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); } \
-        _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+        /* (12 MFMAs, 12 LDS reads, 2 ring writes, 2 global loads per chunk at NS = 3) */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
         if (!C23_NO_BAR) __syncthreads();                                                                              \
         cur = nx;                                                                                                      \
     }
@@ -769,12 +790,21 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const float4 bv = *reinterpret_cast<const float4 *>(bias + ct * 32 + 8 * g + 4 * hl);
-                uint32_t h0, m0, l0, h1, m1, l1;
-                split3x2(fmaxf(acc[ct][4 * g] + bv.x, 0.f), fmaxf(acc[ct][4 * g + 1] + bv.y, 0.f), h0, m0, l0);
-                split3x2(fmaxf(acc[ct][4 * g + 2] + bv.z, 0.f), fmaxf(acc[ct][4 * g + 3] + bv.w, 0.f), h1, m1, l1);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = NS == 3 ? fmaf(acl[ct][4 * g + e], F16_LO_UNSCALE, acc[ct][4 * g + e]) : acc[ct][4 * g + e];
+                uint32_t h0, l0, h1, l1, m_;
+                if constexpr (NS == 3) {
+                    split2x2(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), h0, l0);
+                    split2x2(fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f), h1, l1);
+                } else {
+                    split3x2(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), h0, m_, l0);
+                    split3x2(fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f), h1, m_, l1);
+                }
                 put(0, ct * 4 + g, make_uint2(h0, h1));
-                if (NS == 3) { put(1, ct * 4 + g, make_uint2(m0, m1)); put(2, ct * 4 + g, make_uint2(l0, l1)); }
-                acc[ct][4 * g] = 0.f; acc[ct][4 * g + 1] = 0.f; acc[ct][4 * g + 2] = 0.f; acc[ct][4 * g + 3] = 0.f;
+                if (NS == 3) put(1, ct * 4 + g, make_uint2(l0, l1));
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[ct][4 * g + e] = 0.f; acl[ct][4 * g + e] = 0.f; }
             }
     };
     // ---- conv2
@@ -814,7 +844,8 @@ struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; cons
 
 template <int NS>
 __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
-    constexpr int ASZ = NS * 512, BSZ = 4 * NS * 64, SLOT = ASZ + BSZ;           // uint4 units
+    constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;                   // as in conv23_sp_kernel
+    constexpr int ASZ = NPL * 512, BSZ = 4 * NPL * 64, SLOT = ASZ + BSZ;         // uint4 units
     __shared__ uint4 smem[3 * SLOT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
     // XCD-aware tile order (consecutive workgroup ids go round the 8 XCDs, each with its own 4 MB L2): XCD x takes K slice
@@ -824,7 +855,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     const int ks = xcd & 3, m0 = (w / nth) * 128, n0 = ((xcd >> 2) * nth + w % nth) * 64;
     const int cbase = ks * 12 + (ks < 2 ? ks : 2), count = ks < 2 ? 13 : 12;
     // staging registers as named members (arrays here end up in LDS / scratch: hipcc does not scalarise them)
-    struct St { uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2; };
+    struct St { uint4 a0, a1, a2, a3, b0, b1; };
     // per-thread source pointers, fixed for the whole K loop: chunk c of the activations is an immediate offset
     // (64 B per chunk), the weight pointers advance by one chunk per load() (load() is called in chunk order).
     // Rows past M are clamped to the last row (computed, never stored); a slice with 12 chunks still LOADS a 13th
@@ -834,14 +865,14 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     const uint16_t *pa1 = a.ain + (size_t)r1 * 1600 + (size_t)cbase * 32 + (threadIdx.x & 3) * 8;
     auto ldA = [&](int c, int p, int i) { return *reinterpret_cast<const uint4 *>((i ? pa1 : pa0) + p * a.aplane + c * 32); };
     auto pbq = [&](int q) {
-        const int e = wave + 4 * q, k8 = e / NS, pl = e - k8 * NS;
-        return a.w + ((size_t)(cbase * 4 + k8) * 3 + pl) * a.N + n0 + lane;
+        const int e = wave + 4 * q, k8 = e / NPL, pl = e - k8 * NPL;
+        return a.w + ((size_t)(cbase * 4 + k8) * 3 + P0 + pl) * a.N + n0 + lane;
     };
-    const uint4 *pb0 = pbq(0), *pb1 = pbq(NS == 3 ? 1 : 0), *pb2 = pbq(NS == 3 ? 2 : 0);
+    const uint4 *pb0 = pbq(0), *pb1 = pbq(NPL == 2 ? 1 : 0);
     const size_t bstep = (size_t)12 * a.N;
     auto ldB = [&](int c, int q) {
         (void)c;
-        const uint4 *&pb = q == 0 ? pb0 : q == 1 ? pb1 : pb2;
+        const uint4 *&pb = q == 0 ? pb0 : pb1;
         const uint4 v = *pb;
         pb += bstep;
         return v;
@@ -849,8 +880,8 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     auto load = [&](int c) {
         St r;
         r.a0 = ldA(c, 0, 0); r.a1 = ldA(c, 0, 1); r.b0 = ldB(c, 0);
-        if (NS == 3) { r.a2 = ldA(c, 1, 0); r.a3 = ldA(c, 1, 1); r.a4 = ldA(c, 2, 0); r.a5 = ldA(c, 2, 1); r.b1 = ldB(c, 1); r.b2 = ldB(c, 2); }
-        else { r.a2 = r.a0; r.a3 = r.a0; r.a4 = r.a0; r.a5 = r.a0; r.b1 = r.b0; r.b2 = r.b0; }
+        if (NPL == 2) { r.a2 = ldA(c, 1, 0); r.a3 = ldA(c, 1, 1); r.b1 = ldB(c, 1); }
+        else { r.a2 = r.a0; r.a3 = r.a0; r.b1 = r.b0; }
         return r;
     };
     auto stA_ = [&](int slot, int p, int i, const uint4 v) {
@@ -861,28 +892,29 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
         stA_(slot, 0, 0, r.a0); stA_(slot, 0, 1, r.a1);
         uint4 *d = smem + slot * SLOT + ASZ + wave * 64 + lane;
         d[0] = r.b0;
-        if (NS == 3) { stA_(slot, 1, 0, r.a2); stA_(slot, 1, 1, r.a3); stA_(slot, 2, 0, r.a4); stA_(slot, 2, 1, r.a5); d[256] = r.b1; d[512] = r.b2; }
+        if (NPL == 2) { stA_(slot, 1, 0, r.a2); stA_(slot, 1, 1, r.a3); d[256] = r.b1; }
     };
-    struct Fr { uint4 A[NS]; uint4 W[2][NS]; };           // the fragments of ONE k-step (16 k) of a chunk
+    struct Fr { uint4 A[NPL]; uint4 W[2][NPL]; };         // the fragments of ONE k-step (16 k) of a chunk
     const int row = wave * 32 + j;
     auto readF = [&](int slot, int s) {
         Fr f;
 #pragma unroll
-        for (int p = 0; p < NS; p++) {
+        for (int p = 0; p < NPL; p++) {
             f.A[p] = smem[slot * SLOT + p * 512 + row * 4 + ((2 * s + hl + (row >> 2)) & 3)];
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++) f.W[ct][p] = smem[slot * SLOT + ASZ + ((2 * s + hl) * NS + p) * 64 + ct * 32 + j];
+            for (int ct = 0; ct < 2; ct++) f.W[ct][p] = smem[slot * SLOT + ASZ + ((2 * s + hl) * NPL + p) * 64 + ct * 32 + j];
         }
         return f;
     };
-    f32x16 acc[2] = {{0}, {0}};
+    f32x16 acc[2] = {{0}, {0}}, acl[2] = {{0}, {0}};       // h*h products; h*l + l*h (folded in at the end, x 1 / 4096)
     auto compute = [&](const Fr f) {
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
-#define FB_M(pa, pb) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.A[pa]), __builtin_bit_cast(bf16x8, f.W[ct][pb]), acc[ct], 0, 0, 0)
-            if (NS == 3) { FB_M(2, 0); FB_M(1, 1); FB_M(0, 2); FB_M(1, 0); FB_M(0, 1); }
-            FB_M(0, 0);
-#undef FB_M
+            if constexpr (NS == 3) {
+                acl[ct] = mfma_h(f.A[1], f.W[ct][0], acl[ct]);
+                acl[ct] = mfma_h(f.A[0], f.W[ct][1], acl[ct]);
+                acc[ct] = mfma_h(f.A[0], f.W[ct][0], acc[ct]);
+            } else acc[ct] = mfma_b(f.A[0], f.W[ct][0], acc[ct]);
         }
     };
     St stA = load(0), stB = load(1);
@@ -912,7 +944,9 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
 #undef FB_STEP
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
-        for_rows(m0 + wave * 32, a.M, lane, [&](int r, int mr) { a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = acc[ct][r]; });
+        for_rows(m0 + wave * 32, a.M, lane, [&](int r, int mr) {
+            a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = NS == 3 ? fmaf(acl[ct][r], F16_LO_UNSCALE, acc[ct][r]) : acc[ct][r];
+        });
 }
 
 // relu(bias + sum of the fc1 partials) for one (sample, unit)
