@@ -275,35 +275,109 @@ __device__ void per_apply_updates(const ReplayParams &P, UpdScratch &S, int n, i
     __syncthreads();
 }
 
-// Memory.store for `count` new transitions (BrainPrioritizedReplyDQN.py:121-125, add :50-60)
-__global__ __launch_bounds__(256) void per_store_kernel(ReplayParams P, int count) {
-    extern __shared__ unsigned char smem[];
-    UpdScratch &S = *reinterpret_cast<UpdScratch *>(smem);
+// Memory.store for `count` new transitions (BrainPrioritizedReplyDQN.py:121-125, add :50-60), reference order, parallel over
+// tree NODES.  One vector step stores `count` consecutive data slots, all with the same priority p (np.max over the leaves; storing
+// the maximum never changes it).  The reference walks leaf by leaf: change_j = p - tree[leaf_j], then every ancestor += change_j.
+// The order dependence of those running sums is per NODE: node a ends as ((tree[a] + c_j1) + c_j2) + .. over the leaves under it
+// in increasing j -- a contiguous range of j -- and no node reads another one.  So every touched node gets a thread that adds
+// its range of changes in list order: the same sequence of fp64 additions the reference executes for that node, hence the same
+// bytes, with a critical path of the root's `count` additions instead of count x depth dependent walks (1024 envs, 1 M slots:
+// 457 us -> ~10 us).  max / min heaps: every stored leaf holds p, the global maximum, so maxt = p on every touched node and
+// mint = p on every node whose leaves are all new; the (at most two per level) partially covered edge nodes take the minimum of
+// their children, walked bottom-up by one thread with the untouched siblings' values loaded up front.
+constexpr int PS_CHUNK = 4096;               // leaves per pass (their changes live in LDS)
+
+__global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int count) {
+    __shared__ double chg[PS_CHUNK];
+    __shared__ long long lvl_lo[MAXH];
+    __shared__ int lvl_off[MAXH + 1];
     const int tid = threadIdx.x;
     long long pointer = P.dev->per_pointer, size = P.dev->per_size;
     // first data slot whose leaf sits on the deeper level (heap index >= 2^D - 1)
     const int Dmax = node_depth(2 * P.cap - 2);
     const long long deep0 = ((1ll << Dmax) - 1) - (P.cap - 1);   // may be <= 0: all leaves on one level
-    __syncthreads();
     int done = 0;
     while (done < count) {
         long long n = count - done;
-        if (n > MAXB) n = MAXB;
+        if (n > PS_CHUNK) n = PS_CHUNK;
         if (n > P.cap - pointer) n = P.cap - pointer;             // do not cross the ring wrap
-        if (pointer < deep0 && pointer + n > deep0) n = deep0 - pointer;   // nor the leaf depth change
-        // np.max over all leaves: storing max_p never changes the maximum, re-read per chunk anyway
+        if (pointer < deep0 && pointer + n > deep0) n = deep0 - pointer;   // nor the leaf depth change: one depth per pass
+        // np.max over all leaves: storing max_p never changes the maximum, re-read per pass anyway
         double max_p = P.maxt[0];
         if (max_p == 0) max_p = 1.0;                             // abs_err_upper
-        for (int j = tid; j < (int)n; j += 256) {
-            S.ti[j] = pointer + j + P.cap - 1;
-            S.p[j] = max_p;
+        __syncthreads();                                         // everybody holds the old root maximum; the previous pass is complete
+        const long long leaf_lo = pointer + P.cap - 1, leaf_hi = leaf_lo + n - 1;
+        const int D = node_depth(leaf_lo);
+        // 1) the leaves: change_j = p - old (:63), leaf = p (:64)
+        for (int j = tid; j < (int)n; j += 1024) {
+            const long long leaf = leaf_lo + j;
+            chg[j] = max_p - P.tree[leaf];
+            P.tree[leaf] = max_p; P.maxt[leaf] = max_p; P.mint[leaf] = max_p;
+        }
+        if (tid < D) lvl_lo[tid] = anc(leaf_lo, D, tid);
+        if (tid == 0) {                                          // node tasks flattened root first (the long ones land on different threads)
+            int off = 0;
+            for (int d = 0; d < D; d++) { lvl_off[d] = off; off += (int)(anc(leaf_hi, D, d) - anc(leaf_lo, D, d)) + 1; }
+            lvl_off[D] = off;
         }
         __syncthreads();
-        per_apply_updates<true>(P, S, (int)n, tid, 256);
+        // 2) every touched internal node adds the changes of the leaves under it, in list order (:66-68)
+        const int total = lvl_off[D];
+        for (int task = tid; task < total; task += 1024) {
+            int d = 0;
+            while (d + 1 < D && lvl_off[d + 1] <= task) d++;
+            const long long a = lvl_lo[d] + (task - lvl_off[d]);
+            const int sh = D - d;
+            const long long L = ((a + 1) << sh) - 1, R = ((a + 2) << sh) - 2;      // its descendants on the leaves' level
+            const int jlo = (int)((L > leaf_lo ? L : leaf_lo) - leaf_lo), jhi = (int)((R < leaf_hi ? R : leaf_hi) - leaf_lo);
+            double v = P.tree[a];
+            int j = jlo;
+            for (; j + 8 <= jhi + 1; j += 8) {                   // the LDS reads of a group go out together; the adds stay in order
+                double c[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) c[q] = chg[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v += c[q];
+            }
+            for (; j <= jhi; j++) v += chg[j];
+            P.tree[a] = v;
+            P.maxt[a] = max_p;
+            if (L >= leaf_lo && R <= leaf_hi) P.mint[a] = max_p;     // all its leaves are new
+        }
+        // 3) the minimum heap on the partially covered edge nodes (<= 2 per level), bottom-up, by one thread beside 2)
+        if (tid == 1023) {
+            double m_lo = max_p, m_hi = max_p;                   // values of the level below's edge nodes (the leaves: p)
+            for (int d = D - 1; d >= 0; d--) {
+                const long long lo = anc(leaf_lo, D, d), hi = anc(leaf_hi, D, d), clo = anc(leaf_lo, D, d + 1), chi = anc(leaf_hi, D, d + 1);
+                const int sh1 = D - d - 1;
+                double nv[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const long long a = e ? hi : lo;
+                    double val = INFINITY;
+#pragma unroll
+                    for (int k = 1; k <= 2; k++) {
+                        const long long c = 2 * a + k;
+                        const long long Lc = ((c + 1) << sh1) - 1, Rc = ((c + 2) << sh1) - 2;
+                        double cv;
+                        if (Rc < leaf_lo || Lc > leaf_hi) cv = P.mint[c];                    // untouched: the stored value stands
+                        else if (Lc >= leaf_lo && Rc <= leaf_hi) cv = max_p;                 // all new
+                        else cv = c == clo ? m_lo : m_hi;                                     // the level below's edge node
+                        (void)chi;
+                        val = cv < val ? cv : val;
+                    }
+                    nv[e] = val;
+                    P.mint[a] = val;
+                }
+                m_lo = nv[0]; m_hi = nv[1];
+            }
+        }
+        __threadfence_block();
         pointer = (pointer + n) % P.cap;
         size = size + n < P.cap ? size + n : P.cap;
         done += (int)n;
     }
+    __syncthreads();
     if (tid == 0) { P.dev->per_pointer = pointer; P.dev->per_size = size; }
 }
 
@@ -585,7 +659,7 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
     h->host_steps += 1;
     if (P.kind == FB_REPLAY_PER) {
         if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
-        else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(256), sizeof(UpdScratch), st, P, P.n_envs);
+        else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
         FB_LAUNCH_CHECK();
     }
     return FB_OK;
