@@ -66,7 +66,11 @@ class BrainDQN:
     INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY = INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY
 
     def __init__(self, actionNum, gameName, backend=None, fc_width=512, verbose=True, seed=None,
-                 save_root="./saved_parameters", logs_root="./logs_", record_logs=True):
+                 save_root="./saved_parameters", logs_root="./logs_", record_logs=True, save_replay=False):
+        # save_replay: also checkpoint what the reference forgets (:176-192) -- the replay memory, onlineTimeStep, the current
+        # frame stack and the `random` / np.random generator states -- so that a resumed run does not observe again and continues
+        # the sampled-index stream bit for bit.  Default False = the reference's behaviour.
+        self.save_replay = save_replay
         self.actionNum = actionNum
         self.gameName = gameName
         if backend is None:
@@ -135,6 +139,17 @@ class BrainDQN:
                 self.gameTimes = _load_scalar(f)
                 self.timeStep = _load_scalar(f)
                 self.epsilon = _load_scalar(f)
+        extra = ckpt[:-4] + "-replay.npz"
+        if self.save_replay and os.path.exists(extra) and hasattr(self.replayMemory, "load_state_blob"):
+            e = np.load(extra)
+            self.replayMemory.load_state_blob(e["replay"])
+            self.onlineTimeStep, self._n_stored = int(e["scalars"][0]), int(e["scalars"][1])
+            self.currentState = e["currentState"]
+            st = e["py_random"]
+            random.setstate((int(st[0]), tuple(int(x) for x in st[1:626]), None if st[626] < 0 else float(e["py_gauss"][0])))
+            np.random.set_state(("MT19937", e["np_keys"], int(e["np_pos"][0]), int(e["np_pos"][1]), float(e["np_gauss"][0])))
+            if self.verbose:
+                print("Successfully loaded the replay memory:", extra)
         return True
 
     def save_checkpoint(self):
@@ -151,6 +166,13 @@ class BrainDQN:
             pickle.dump(self.gameTimes, f)
             pickle.dump(self.timeStep, f)
             pickle.dump(self.epsilon, f)
+        if self.save_replay and hasattr(self.replayMemory, "state_blob"):
+            ver, keys, gauss = random.getstate()
+            nps = np.random.get_state()
+            np.savez(os.path.join(self.save_path, name[:-4] + "-replay.npz"), replay=self.replayMemory.state_blob(),
+                     scalars=np.array([self.onlineTimeStep, self._n_stored], np.int64), currentState=self.currentState,
+                     py_random=np.array([ver, *keys, -1 if gauss is None else 1], np.int64), py_gauss=np.array([gauss or 0.0]),
+                     np_keys=nps[1], np_pos=np.array([nps[2], nps[3]], np.int64), np_gauss=np.array([nps[4]]))
 
     # ------------------------------------------------------------------ reference surface
     def setInitState(self, observ):

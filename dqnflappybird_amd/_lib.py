@@ -55,6 +55,9 @@ SIGNATURES = {
     "fb_replay_set_per_mode": [_vp, _i],
     "fb_replay_size": [_vp, _vp],
     "fb_replay_per_tree": [_vp] * 5,
+    "fb_replay_state_bytes": [_vp, _vp],
+    "fb_replay_save_state": [_vp, _vp, _sz],
+    "fb_replay_load_state": [_vp, _vp, _sz],
     "fb_qnet_create": [_i, _i, _i, _i, _vp],
     "fb_qnet_destroy": [_vp],
     "fb_qnet_num_params": [_vp, _vp],

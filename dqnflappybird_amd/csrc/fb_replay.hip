@@ -824,3 +824,91 @@ extern "C" int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *dat
     if (beta) *beta = d.beta;
     return FB_OK;
 }
+
+// ------------------------------------------------------------------ checkpoint of the memory
+// The reference saves the network and three scalars and FORGETS the replay memory (BrainDQN.py:176-192,227-233: a resumed run
+// observes for 1 000 steps again).  These three calls let a caller keep it: one opaque host blob holds the frame ring, the
+// per-transition action / reward / terminal rows, the device-side counters (steps, SumTree pointer / size / beta, Philox call
+// counter), the sampler's MT19937 state and, for a prioritized memory, the three heaps -- everything a later
+// fb_replay_sample / gather / push needs to continue bit for bit.  Synchronous; the blob is only valid for a memory created with
+// the same capacity, env count and kind.
+namespace {
+struct ReplayBlobHeader {
+    uint64_t magic, version;
+    int64_t cap, host_steps;
+    int32_t n_envs, kind, t_f, rng_kind, per_mode, pad;
+    uint32_t seed_lo, seed_hi;
+    uint64_t total_bytes;
+};
+constexpr uint64_t REPLAY_BLOB_MAGIC = 0x5052424644514e46ull;        // "FNQDFBRP"
+struct BlobPart { void *dev; size_t bytes; };
+static int blob_parts(fb_replay *h, BlobPart *parts) {
+    const ReplayParams &P = h->P;
+    const size_t slots = (size_t)P.t_f * P.n_envs;
+    int n = 0;
+    parts[n++] = BlobPart{P.dev, sizeof(ReplayDev)};
+    parts[n++] = BlobPart{P.mt, sizeof(FbMT)};
+    parts[n++] = BlobPart{P.bits, slots * WORDS * sizeof(unsigned long long)};
+    parts[n++] = BlobPart{P.act, slots};
+    parts[n++] = BlobPart{P.rew, slots * sizeof(float)};
+    parts[n++] = BlobPart{P.term, slots};
+    if (P.kind == FB_REPLAY_PER) {
+        const size_t nb = sizeof(double) * (size_t)(2 * P.cap - 1);
+        parts[n++] = BlobPart{P.tree, nb}; parts[n++] = BlobPart{P.maxt, nb}; parts[n++] = BlobPart{P.mint, nb};
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" int fb_replay_state_bytes(fb_replay_t h, size_t *bytes_host) {
+    FB_REQUIRE(h && bytes_host, "fb_replay_state_bytes: NULL argument");
+    BlobPart parts[9];
+    const int n = blob_parts(h, parts);
+    size_t total = sizeof(ReplayBlobHeader);
+    for (int i = 0; i < n; i++) total += (parts[i].bytes + 15) & ~(size_t)15;
+    *bytes_host = total;
+    return FB_OK;
+}
+
+extern "C" int fb_replay_save_state(fb_replay_t h, void *blob_host, size_t bytes) {
+    FB_REQUIRE(h && blob_host, "fb_replay_save_state: NULL argument");
+    size_t need = 0;
+    fb_replay_state_bytes(h, &need);
+    FB_REQUIRE(bytes >= need, "fb_replay_save_state: the blob needs %zu bytes, %zu given", need, bytes);
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    ReplayBlobHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.magic = REPLAY_BLOB_MAGIC; hd.version = 1; hd.cap = h->P.cap; hd.host_steps = h->host_steps; hd.n_envs = h->P.n_envs; hd.kind = h->P.kind;
+    hd.t_f = h->P.t_f; hd.rng_kind = h->P.rng_kind; hd.per_mode = h->per_mode; hd.seed_lo = h->P.seed_lo; hd.seed_hi = h->P.seed_hi; hd.total_bytes = need;
+    memcpy(blob_host, &hd, sizeof(hd));
+    BlobPart parts[9];
+    const int n = blob_parts(h, parts);
+    char *o = (char *)blob_host + sizeof(hd);
+    for (int i = 0; i < n; i++) {
+        FB_CHECK_HIP(hipMemcpy(o, parts[i].dev, parts[i].bytes, hipMemcpyDeviceToHost));
+        o += (parts[i].bytes + 15) & ~(size_t)15;
+    }
+    return FB_OK;
+}
+
+extern "C" int fb_replay_load_state(fb_replay_t h, const void *blob_host, size_t bytes) {
+    FB_REQUIRE(h && blob_host && bytes >= sizeof(ReplayBlobHeader), "fb_replay_load_state: bad argument");
+    ReplayBlobHeader hd;
+    memcpy(&hd, blob_host, sizeof(hd));
+    size_t need = 0;
+    fb_replay_state_bytes(h, &need);
+    FB_REQUIRE(hd.magic == REPLAY_BLOB_MAGIC && hd.version == 1, "fb_replay_load_state: not a replay checkpoint");
+    FB_REQUIRE(hd.cap == h->P.cap && hd.n_envs == h->P.n_envs && hd.kind == h->P.kind && hd.t_f == h->P.t_f && hd.total_bytes == need && bytes >= need,
+               "fb_replay_load_state: the checkpoint is of a memory with capacity %lld, %d envs, kind %d; this one has %lld, %d, %d",
+               (long long)hd.cap, hd.n_envs, hd.kind, (long long)h->P.cap, h->P.n_envs, h->P.kind);
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    BlobPart parts[9];
+    const int n = blob_parts(h, parts);
+    const char *o = (const char *)blob_host + sizeof(hd);
+    for (int i = 0; i < n; i++) {
+        FB_CHECK_HIP(hipMemcpy(parts[i].dev, o, parts[i].bytes, hipMemcpyHostToDevice));
+        o += (parts[i].bytes + 15) & ~(size_t)15;
+    }
+    h->host_steps = hd.host_steps; h->P.rng_kind = hd.rng_kind; h->per_mode = hd.per_mode; h->P.seed_lo = hd.seed_lo; h->P.seed_hi = hd.seed_hi;
+    return FB_OK;
+}

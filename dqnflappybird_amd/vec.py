@@ -218,6 +218,19 @@ class VecReplay:
         L.check(L.lib().fb_replay_size(self.h, C.byref(v)), "fb_replay_size")
         return v.value
 
+    def state_blob(self):
+        """The whole memory as one numpy uint8 blob (fb_replay_save_state): frame ring, a / r / t rows, counters, sampler
+        generator, SumTree heaps -- what a resumed run needs to continue the index stream bit for bit."""
+        n = C.c_size_t()
+        L.check(L.lib().fb_replay_state_bytes(self.h, C.byref(n)), "fb_replay_state_bytes")
+        blob = np.empty(n.value, np.uint8)
+        L.check(L.lib().fb_replay_save_state(self.h, L.ptr(blob), n.value), "fb_replay_save_state")
+        return blob
+
+    def load_state_blob(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        L.check(L.lib().fb_replay_load_state(self.h, L.ptr(blob), blob.size), "fb_replay_load_state")
+
     def per_state(self, want_tree=True):
         tree = np.empty(2 * self.capacity - 1, np.float64) if want_tree else None
         ptr_, size, beta = C.c_int64(), C.c_int64(), C.c_double()

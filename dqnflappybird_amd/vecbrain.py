@@ -70,6 +70,7 @@ class VecBrain:
         self.replay.reset(self.env.frame_bits)
         self.stats = self.env.track_stats()                  # [episodes, score sum, score max, pipes passed], kept by the env kernel
         self.last_loss = None
+        self.dtype = "f32"
         # uniform replay: the whole step is one host call (fb_vec_step), with the head, random.sample and the Memory append
         # riding in the env launch; PER keeps the separate calls (its sample returns the importance weights)
         self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad) if algo != "per" else None
@@ -120,6 +121,35 @@ class VecBrain:
             self.train_step(idx)
         self.timeStep += 1
         self.onlineTimeStep += 1
+
+    # ------------------------------------------------------------------ checkpoint / resume of the WHOLE loop
+    def save(self, path):
+        """Everything the device-resident loop needs to continue bit for bit: both nets + Adam slots (what the reference saves,
+        BrainDQN.py:227-233), the three scalars, AND what it forgets (:176-192): the replay memory (frame ring, a / r / t, sampler
+        generator, SumTree), onlineTimeStep, every env's state and the agents' frame stacks."""
+        import numpy as np
+        m, v, pows = self.net.adam_state()
+        host = lambda t: t.cpu().numpy()
+        np.savez(path, online=host(self.net.store_params(0)), target=host(self.net.store_params(1)), adam_m=host(m), adam_v=host(v),
+                 beta_pows=np.asarray(pows, np.float32), env_state=self.env.get_state(), nib=host(self.nib), stats=host(self.stats),
+                 replay=self.replay.state_blob(), scalars=np.array([self.timeStep, self.onlineTimeStep], np.int64),
+                 epsilon=np.array([self.epsilon], np.float64))
+
+    def load(self, path):
+        import numpy as np
+        import torch
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        self.net.load_params(z["online"], 0)
+        self.net.load_params(z["target"], 1)
+        self.net.set_adam_state(dev(z["adam_m"]), dev(z["adam_v"]), z["beta_pows"])
+        self.env.set_state(z["env_state"])
+        self.nib.copy_(dev(z["nib"]))
+        self.stats.copy_(dev(z["stats"]))
+        self.replay.load_state_blob(z["replay"])
+        self.timeStep, self.onlineTimeStep = int(z["scalars"][0]), int(z["scalars"][1])
+        self.epsilon = float(z["epsilon"][0])
+        torch.cuda.synchronize()
 
     def run(self, steps, log_every=100):
         for i in range(steps):

@@ -180,6 +180,13 @@ int fb_replay_set_per_mode(fb_replay_t h, int mode);
 /* host-side queries (synchronous): len(replayMemory); PER: tree copy f64[2*cap-1] [host] */
 int fb_replay_size(fb_replay_t h, int64_t *size_host);
 int fb_replay_per_tree(fb_replay_t h, double *tree_host, int64_t *data_pointer, int64_t *size, double *beta);
+/* Checkpoint of the memory -- what the reference forgets (BrainDQN.py:176-192,227-233 save the network and three scalars; a
+ * resumed run observes for OBSERVE steps again).  One opaque [host] blob of fb_replay_state_bytes() bytes holds the frame ring, the
+ * action / reward / terminal rows, the counters, the sampler's generator state and the SumTree heaps: after fb_replay_load_state
+ * into a memory created with the same capacity / env count / kind, sample / gather / push continue bit for bit.  Synchronous. */
+int fb_replay_state_bytes(fb_replay_t h, size_t *bytes_host);
+int fb_replay_save_state(fb_replay_t h, void *blob_host, size_t bytes);
+int fb_replay_load_state(fb_replay_t h, const void *blob_host, size_t bytes);
 
 /* ------------------------------------------------------------------ Q network
  *   network        BrainDQN.py:119-155 (conv 8x8/4 -> pool -> conv 4x4/2 -> conv 3x3/1 -> fc -> A)

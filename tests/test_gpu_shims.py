@@ -151,6 +151,70 @@ def test_checkpoint_resume_on_device(torch_cuda, oracle, tmp_path):
     assert torch_cuda.equal(a.net.forward(st), b.net.forward(st))
 
 
+def test_checkpoint_with_replay_memory_resumes_the_index_stream(torch_cuda, oracle, tmp_path):
+    """save_replay=True keeps what the reference forgets (BrainDQN.py:176-192): replay memory, onlineTimeStep, frame stack and the
+    generators.  The resumed Brain does not observe again and, fed the same frames, draws the same minibatch indices, takes the same
+    actions and ends with the same parameters as the one that never stopped."""
+    import random
+    from dqnflappybird_amd.BrainDQN import BrainDQN
+    from tests.test_brain_host_logic import frames_source
+    root = str(tmp_path / "saved_parameters")
+
+    def run(brain, env, n, log):
+        for _ in range(n):
+            act = brain.getAction()
+            obs, r, t, s = env(int(act[1]))
+            brain.setPerception(obs, act, r, t, s)
+            log.append((int(act[1]), float(brain._be.host(brain.lost).reshape(-1)[0]) if brain.lost is not None else None))
+
+    random.seed(4); np.random.seed(4)
+    first, env_a = frames_source(oracle, 2)
+    a = BrainDQN(2, 'bird', verbose=False, seed=5, save_root=root, save_replay=True)
+    a.OBSERVE, a.BATCH_SIZE = 8., 8
+    a.setInitState(first)
+    log_a = []
+    run(a, env_a, 14, log_a)
+    a.save_checkpoint()
+    tail_a = []
+    run(a, env_a, 10, tail_a)
+    # the same environment, replayed to the checkpoint's position for the resumed brain
+    _, env_b = frames_source(oracle, 2)
+    for act, _ in log_a:
+        env_b(act)
+    random.seed(999); np.random.seed(999)                                # the checkpoint restores the generators
+    b = BrainDQN(2, 'bird', verbose=False, seed=99, save_root=root, save_replay=True)
+    b.OBSERVE, b.BATCH_SIZE = 8., 8
+    assert b.onlineTimeStep == 14 and len(b) == 14                       # no second OBSERVE phase
+    tail_b = []
+    run(b, env_b, 10, tail_b)
+    assert tail_a == tail_b                                              # actions and losses step by step
+    assert torch_cuda.equal(a.net.store_params(0), b.net.store_params(0))
+
+
+def test_vecbrain_save_load_continues_bit_for_bit(torch_cuda, tmp_path):
+    """VecBrain.save / load: the device-resident loop (256 envs) resumed from a checkpoint reproduces the actions, the sampled
+    indices and the parameters of the run that never stopped -- env states, frame stacks, ring, sampler generator, Adam slots."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vecbrain import VecBrain
+    kw = dict(algo="nature", batch=32, capacity=20000, observe=6, seed=3, replace_target_iter=4)
+    a = VecBrain(256, **kw)
+    a.run(20, log_every=0)
+    a.save(str(tmp_path / "ck"))
+    eps_saved = a.epsilon
+    ta = []
+    for _ in range(12):
+        a.step(); ta.append((a.one_step.actions.clone(), a.one_step.idx.clone(), a.one_step.loss.clone()))
+    b = VecBrain(256, **dict(kw, seed=77))                               # different games, weights and generator until load()
+    b.load(str(tmp_path / "ck"))
+    assert (b.timeStep, b.onlineTimeStep, b.epsilon) == (20, 20, eps_saved)
+    b.seed = a.seed                                                      # the acting stream's key is a constructor argument, not state
+    for i in range(12):
+        b.step()
+        assert torch.equal(b.one_step.actions, ta[i][0]) and torch.equal(b.one_step.idx, ta[i][1]) and torch.equal(b.one_step.loss, ta[i][2]), i
+    assert torch.equal(a.net.store_params(0), b.net.store_params(0)) and torch.equal(a.net.store_params(1), b.net.store_params(1))
+    assert (a.env.get_state() == b.env.get_state()).all() and len(a.replay) == len(b.replay)
+
+
 @pytest.mark.parametrize("N", [7, 64, 300])      # < 256: the fp32-MFMA kernels; >= 256: the split-bf16 acting kernels
 def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cuda, N):
     """The env kernel's running 4-frame nibble state == the replay ring's currentState (BrainDQN.py:68,238-239),
