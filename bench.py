@@ -35,7 +35,7 @@ FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64
             "conv3_kernel": 2 * 25 * 64 * 576, "fc1_kernel": 2 * 1600 * 512, "head_kernel": 2 * 512 * 2}
 BWD_FLOP = {"fc1_bwd_kernel": 2 * 2 * 1600 * 512,                 # dW + dX in one launch
             "conv3_bwd_kernel": 2 * 2 * 25 * 576 * 64, "conv2_bwd_kernel": 2 * 2 * 25 * 512 * 64,
-            "conv1_dw_kernel": 2 * 400 * 256 * 32}
+            "conv1_dw2_kernel": 2 * 400 * 256 * 32}
 GATHER_BYTES = 102_417          # per sampled transition
 ADAM_BYTES = 28                 # per parameter
 ENV_BYTES = 6_400 + 64          # per env-step

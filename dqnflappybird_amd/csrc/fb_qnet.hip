@@ -41,7 +41,7 @@ constexpr int MAXTB = 256;
 
 
 struct Slice { const float *params; const uint8_t *states; int s_off, count; const uint16_t *w1s; };
-struct Slices { Slice s[3]; };
+struct Slices { Slice s[3]; int rb; };    // rb: bf16 training (fb_qnet_set_train_dtype): GEMM operands are rounded to bf16
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -99,12 +99,14 @@ __device__ __forceinline__ void reduce_rows(const f32x16 &acc, float *red, int w
 // pins a loaded value in a register where it stands: without it LLVM sinks a load into the (even wave-uniform) branch
 // that uses it, which brings the vmcnt(0)-per-load behaviour back
 __device__ __forceinline__ void keep(float &x) { asm volatile("" : "+v"(x)); }
+// bf16 training: an operand as the nearest bf16 number (products of two such are exact in the fp32 accumulation)
+__device__ __forceinline__ float rbf(float x, bool rb) { return rb ? (float)(__bf16)x : x; }
 __device__ __forceinline__ void keep(int &x) { asm volatile("" : "+v"(x)); }
 
 // KH MFMAs: A from a contiguous run of KH floats (or zeros), B from a column with stride bstride
 template <int KH>
 __device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
-                                            int bstride, f32x16 &acc) {
+                                            int bstride, f32x16 &acc, bool rb = false) {
     float a[KH], b[KH];
 #pragma unroll
     for (int q = 0; q < KH / 4; q++) {
@@ -116,13 +118,13 @@ __device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool
 #pragma unroll
     for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
 #pragma unroll
-    for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
+    for (int t = 0; t < KH; t++) acc = mfma(rbf(a[t], rb), rbf(b[t], rb), acc);
 }
 
 // KH MFMAs with both operands as contiguous runs
 template <int KH>
 __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool ok, const float *__restrict__ brun,
-                                            f32x16 &acc) {
+                                            f32x16 &acc, bool rb = false) {
     float a[KH], b[KH];
 #pragma unroll
     for (int q = 0; q < KH / 4; q++) {
@@ -134,7 +136,7 @@ __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool
 #pragma unroll
     for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
 #pragma unroll
-    for (int t = 0; t < KH; t++) acc = mfma(a[t], b[t], acc);
+    for (int t = 0; t < KH; t++) acc = mfma(rbf(a[t], rb), rbf(b[t], rb), acc);
 }
 
 // ================================================================== forward
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__re
     const float *arun = p1 + (((size_t)(s.s_off + (ok ? b : 0)) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
     const float *bcol = s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j;
     f32x16 acc = {0};
-    mma_run_col<32>(arun, ok, bcol, 64, acc);
+    mma_run_col<32>(arun, ok, bcol, 64, acc, sl.rb);
     const float bias = s.params[OFF_B2 + n0 + j];
     reduce_rows<8>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
 }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__re
     const float *arun = h2 + ((size_t)(s.s_off + (ok ? b : 0)) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
     const float *bcol = s.params + OFF_W3 + ((size_t)(wave * 64) + 32 * hl) * 64 + n0 + j;
     f32x16 acc = {0};
-    mma_run_col<32>(arun, ok, bcol, 64, acc);
+    mma_run_col<32>(arun, ok, bcol, 64, acc, sl.rb);
     const float bias = s.params[OFF_B3 + n0 + j];
     reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
 }
@@ -538,10 +540,15 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int l) {
     v[0] = b1 ? ra : x0; v[1] = b1 ? rb : x1; v[2] = b1 ? x2 : ra; v[3] = b1 ? x3 : rb;
 }
 
+// Training on >= 256 states runs its forward through these kernels too: `side` then names up to two further state blocks (the
+// minibatch's s and s' are separate buffers: state b lives in block b / per) and the fp32 copies the backward pass reads -- the
+// pooled activations and the position of each pool's maximum (first maximum, like conv1_pool_kernel).
+struct C1Side { const uint8_t *st1, *st2; int per; float *p1; uint8_t *amax; };
+
 template <bool NIB>
 __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
                                                                   size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC,
-                                                                  const unsigned *__restrict__ pver, const unsigned *__restrict__ wver) {
+                                                                  const unsigned *__restrict__ pver, const unsigned *__restrict__ wver, C1Side side) {
     __shared__ uint4 wl[2 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
     const int bid = blockIdx.x, nblk = gridDim.x;
@@ -566,12 +573,15 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
     const float bias = s.params[OFF_B1 + j];
     auto fetch = [&](int tile, Raw (&raw)[16]) {
         const int P0 = tile * 8 + pp, P = P0 < npool ? P0 : 0;       // rows past the end compute on state 0 and are not stored
-        const int b = P / 100, rem = P - b * 100, py = rem / 10, px = rem - py * 10;
+        int b = P / 100;
+        const int rem = P - b * 100, py = rem / 10, px = rem - py * 10;
         const int oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+        const uint8_t *sbase = s.states;
+        if (side.per) { const int blk = b / side.per; b -= blk * side.per; sbase = blk == 0 ? s.states : blk == 1 ? side.st1 : side.st2; }
         if constexpr (NIB) {
             // the nibble image carries conv1's SAME padding (FB_NIB_*): every tap is base + ky * pitch + 2 * kq, no bounds
             // check, no select -- 16 byte loads at immediate offsets from one address
-            const uint8_t *base = s.states + (size_t)b * FB_NIB_STRIDE + (4 * oy) * FB_NIB_PITCH + 3 + 2 * ox + hl;
+            const uint8_t *base = sbase + (size_t)b * FB_NIB_STRIDE + (4 * oy) * FB_NIB_PITCH + 3 + 2 * ox + hl;
 #pragma unroll
             for (int ky = 0; ky < 8; ky++)
 #pragma unroll
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
         for (int ky = 0; ky < 8; ky++) {
             const int iy = oy * 4 + ky - 2;
             const bool rowok = P < npool && iy >= 0 && iy < 80;
-            const uint8_t *row = s.states + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * (NIB ? 1 : 8) / 2;
+            const uint8_t *row = sbase + (((size_t)b * 80 + (rowok ? iy : 0)) * 80) * (NIB ? 1 : 8) / 2;
 #pragma unroll
             for (int kq = 0; kq < 2; kq++) {
                 const int ix = ox * 4 - 2 + 4 * kq + 2 * hl;
@@ -619,8 +629,26 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
         float o4[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) o4[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias, 0.f);
+        float am4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (side.amax) {                             // argmax of relu(x + bias) over the window, first maximum (conv1_pool_kernel's rule)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float bv = fmaxf(acc[4 * g] + bias, 0.f);
+                int best = 0;
+#pragma unroll
+                for (int q = 1; q < 4; q++) { const float v = fmaxf(acc[4 * g + q] + bias, 0.f); if (v > bv) { bv = v; best = q; } }
+                am4[g] = __int_as_float(best);
+            }
+            quad_transpose(am4, j & 3);
+        }
         quad_transpose(o4, j & 3);
         const int Pp = tile * 8 + 2 * (j & 3) + hl;
+        if (side.p1 && Pp < npool) {
+            const size_t so = ((size_t)s.s_off * 100 + Pp) * 32 + 4 * (j >> 2);
+            *reinterpret_cast<float4 *>(side.p1 + so) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            *reinterpret_cast<uint32_t *>(side.amax + so) = (uint32_t)__float_as_int(am4[0]) | (uint32_t)__float_as_int(am4[1]) << 8 |
+                                                             (uint32_t)__float_as_int(am4[2]) << 16 | (uint32_t)__float_as_int(am4[3]) << 24;
+        }
         uint32_t hi[2], lo[2], m_, l_;
         if (nsplit == 3) { split2x2(o4[0], o4[1], hi[0], lo[0]); split2x2(o4[2], o4[3], hi[1], lo[1]); }      // fp16 h / l planes
         else { split3x2(o4[0], o4[1], hi[0], m_, l_); split3x2(o4[2], o4[3], hi[1], m_, l_); lo[0] = lo[1] = 0u; }     // one bf16 plane
@@ -649,6 +677,7 @@ struct C23Args {
     uint16_t *a3s; size_t pl3;               // conv3 output planes [3][n*25][64]
     int n;
     const unsigned *pver; unsigned *wver;    // whole forward plans: the conv1 launch in front re-split the weights if these differed
+    float *h2o, *h3o;                        // training: fp32 copies of conv2's / conv3's output rows [n*25][64] for the backward pass, or NULL
 };
 
 #ifndef C23_NO_LDSR
@@ -784,7 +813,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
         cur = nx;                                                                                                      \
     }
     // relu(acc + bias) of this lane's 32 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half)
-    auto epilogue = [&](const float *__restrict__ bias, auto put) {
+    auto epilogue = [&](const float *__restrict__ bias, float *__restrict__ side, auto put) {
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
@@ -803,6 +832,9 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
                 }
                 put(0, ct * 4 + g, make_uint2(h0, h1));
                 if (NS == 3) put(1, ct * 4 + g, make_uint2(l0, l1));
+                if (side && rowok && bl < nloc)
+                    *reinterpret_cast<float4 *>(side + ((size_t)s0 * 25 + ml) * 64 + ct * 32 + 8 * g + 4 * hl) =
+                        make_float4(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f));
 #pragma unroll
                 for (int e = 0; e < 4; e++) { acc[ct][4 * g + e] = 0.f; acl[ct][4 * g + e] = 0.f; }
             }
@@ -815,7 +847,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     }
     // its output pixel ml (= bl * 25 + oy * 5 + ox), 64 channels = 8 pieces, piece q on q ^ ((ml >> 1) & 7); aliases the input
     // images, which every wave has finished reading (barrier at the end of chunk 15)
-    epilogue(a.b2, [&](int p, int piece, uint2 v) {
+    epilogue(a.b2, a.h2o, [&](int p, int piece, uint2 v) {
         if (rowok) reinterpret_cast<uint2 *>(smem + p * C2_P + ml * 8 + (piece ^ ((ml >> 1) & 7)))[hl] = v;
     });
     __syncthreads();
@@ -827,7 +859,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
         FB_STEP(16 + c + 1, bstB, a3(c + 2), c + 2 < 18);
     }
 #undef FB_STEP
-    epilogue(a.b3, [&](int p, int piece, uint2 v) {
+    epilogue(a.b3, a.h3o, [&](int p, int piece, uint2 v) {
         if (rowok && bl < nloc)
             *reinterpret_cast<uint2 *>(a.a3s + p * a.pl3 + ((size_t)s0 * 25 + ml) * 64 + piece * 8 + 4 * hl) = v;
     });
@@ -1212,8 +1244,8 @@ __global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
     for (int t = 0; t < 25; t++) { keep(av[t].x); keep(av[t].y); }
 #pragma unroll
     for (int t = 0; t < (FK_ABL == 1 ? 1 : 25); t++) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv[2 * t], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv[2 * t + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(rbf(av[t].x, a.sl.rb), rbf(bv[2 * t], a.sl.rb), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rbf(av[t].y, a.sl.rb), rbf(bv[2 * t + 1], a.sl.rb), acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) red[(wave * 4 + q) * 64 + lane] = acc0[q] + acc1[q];
@@ -1247,7 +1279,7 @@ __global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
 // gradients (W_q, b_q, W_v, b_v, b_fc1) come from the first dW workgroup of every column block; loss / abs_err / y and the Adam
 // tick from workgroup 0.  Same arithmetic per element as loss_head_kernel + fc1_bwd_kernel.
 struct Bw1Args {
-    int algo, B, FC, A, dueling, stot, n_dx;
+    int algo, B, FC, A, dueling, stot, n_dx, rb;
     NetOff off;
     const float *params, *pnext, *ptarget;   // online net; the nets slice 1 (s') and slice 2 (Double: s' again) went through
     const float *hf, *qpart, *h3;
@@ -1494,7 +1526,9 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
             for (int q = 0; q < 8; q++) {
                 if (4 * q < kh && BW_ABL != 3) {
                     const float4 x = xa[q], w = pre_w[q];
-                    acc = mfma(x.x, w.x, acc); acc = mfma(x.y, w.y, acc); acc = mfma(x.z, w.z, acc); acc = mfma(x.w, w.w, acc);
+                    const bool rb = L.rb;
+                    acc = mfma(rbf(x.x, rb), rbf(w.x, rb), acc); acc = mfma(rbf(x.y, rb), rbf(w.y, rb), acc);
+                    acc = mfma(rbf(x.z, rb), rbf(w.z, rb), acc); acc = mfma(rbf(x.w, rb), rbf(w.w, rb), acc);
                 }
             }
         }
@@ -1527,13 +1561,13 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
         for (int t = 0; t < 16; t++) {                                   // samples 0..31: A operands pre-loaded at the top
             const int b = 2 * t + hl;
             const float w = dh[(b < B ? b : 0) * BW_DW_ROW + jj];
-            acc = mfma(b < B ? pre_a[t] : 0.f, b < B ? w : 0.f, acc);
+            acc = mfma(b < B ? rbf(pre_a[t], L.rb) : 0.f, b < B ? rbf(w, L.rb) : 0.f, acc);
         }
 #pragma unroll 4
         for (int t = 16; t < (B + 1) / 2; t++) {
             const int b = 2 * t + hl, bc = b < B ? b : 0;
             const float x = L.h3[(size_t)bc * 1600 + kt * 32 + i], w = dh[bc * BW_DW_ROW + jj];
-            acc = mfma(b < B ? x : 0.f, b < B ? w : 0.f, acc);
+            acc = mfma(b < B ? rbf(x, L.rb) : 0.f, b < B ? rbf(w, L.rb) : 0.f, acc);
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) L.grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + jj] = acc[r];
@@ -1588,7 +1622,7 @@ __global__ __launch_bounds__(512) void fc1_bwd2_kernel(Bw1Args L) {
 // ================================================================== backward
 // dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
 __device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h3, const float *__restrict__ dhf,
-                                            float *__restrict__ grad, int B, int FC) {
+                                            float *__restrict__ grad, int B, int FC, bool rb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int nt_n = FC / 32, tile = blk * 8 + wave;
     if (tile >= 50 * nt_n) return;
@@ -1599,7 +1633,7 @@ __device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h
         const int b = 2 * t + hl;
         const int bc = b < B ? b : 0;
         const float a = h3[(size_t)bc * 1600 + kt * 32 + i], bb = dhf[(size_t)bc * FC + nt * 32 + j];
-        acc = mfma(b < B ? a : 0.f, b < B ? bb : 0.f, acc);
+        acc = mfma(b < B ? rbf(a, rb) : 0.f, b < B ? rbf(bb, rb) : 0.f, acc);
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + j] = acc[r];
@@ -1607,7 +1641,7 @@ __device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h
 
 // dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 8 waves split n
 __device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ h3,
-                                            const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC) {
+                                            const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC, bool rb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int mt = blk / 50, kt = blk - mt * 50;
     const int m = mt * 32 + i;
@@ -1617,8 +1651,8 @@ __device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__
     const float *brun = params + OFF_WF1 + (size_t)(kt * 32 + j) * FC + nbeg;
     f32x16 acc = {0};
     int c = 0;
-    for (; c + 32 <= kh; c += 32) mma_run_run<32>(arun + c, ok, brun + c, acc);
-    for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc);
+    for (; c + 32 <= kh; c += 32) mma_run_run<32>(arun + c, ok, brun + c, acc, rb);
+    for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc, rb);
     reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
         const size_t o = (size_t)mr * 1600 + kt * 32 + j;
         dh3[o] = h3[o] > 0.f ? v : 0.f;
@@ -1639,7 +1673,7 @@ template <> struct DwGeom<3> { static constexpr int OH = 5, OW = 5, IH = 5, IW =
 template <int LAYER>
 __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *red, int B, const float *__restrict__ x,
                                              const uint8_t *__restrict__ xu8, const float *__restrict__ dy,
-                                             const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride) {
+                                             const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, bool rb = false) {
     using G = DwGeom<LAYER>;
     constexpr int COT = G::CO / 32, WTILES = G::CELLS * G::CIT * COT, OPIX = G::OH * G::OW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
@@ -1707,7 +1741,7 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
             a[t] = bias_tile ? (mok[t] && i == 0 ? 1.f : 0.f) : (mok[t] && in[t] ? xv[t] : 0.f);
         }
 #pragma unroll
-        for (int t = 0; t < 16; t++) acc = mfma(a[t], bb[t], acc);
+        for (int t = 0; t < 16; t++) acc = mfma(rbf(a[t], rb), rbf(bb[t], rb), acc);
     }
     float *o = slabs + zslab * slab_stride;
     reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
@@ -1722,7 +1756,7 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
 
 // conv3 data gradient -> dh2 (masked by relu2); 9 waves = 9 cells
 __device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh3,
-                                              const float *__restrict__ h2, float *__restrict__ dh2, int B) {
+                                              const float *__restrict__ h2, float *__restrict__ dh2, int B, bool rb = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int M = B * 25, tile = blk >> 1, c0 = (blk & 1) * 32;
     const int ky = wave / 3, kx = wave - ky * 3;
@@ -1732,7 +1766,7 @@ __device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *
     const float *arun = dh3 + ((size_t)(ok ? b : 0) * 25 + (ok ? oy * 5 + ox : 0)) * 64 + 32 * hl;
     const float *brun = params + OFF_W3 + ((size_t)(wave * 64) + c0 + j) * 64 + 32 * hl;
     f32x16 acc = {0};
-    mma_run_run<32>(arun, ok, brun, acc);
+    mma_run_run<32>(arun, ok, brun, acc, rb);
     reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? v : 0.f; });
 }
 
@@ -1741,7 +1775,7 @@ __device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *
 // class (blockIdx.y) from the 25 pixels of that class per sample, and the 4 waves take the 4 live cells --
 // a quarter of the MFMAs a class-blind tiling would issue.
 __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh2,
-                                              const float *__restrict__ p1, float *__restrict__ dp1, int B) {
+                                              const float *__restrict__ p1, float *__restrict__ dp1, int B, bool rb = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
     const int M = B * 25, tile = blk >> 2, py = (blk >> 1) & 1, px = blk & 1;
     const int ky = ((py + 1) & 1) + 2 * (wave >> 1), kx = ((px + 1) & 1) + 2 * (wave & 1);
@@ -1753,7 +1787,7 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
     const float *arun = dh2 + ((size_t)(ok ? b : 0) * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
     const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
     f32x16 acc = {0};
-    if (wave < 4) mma_run_run<32>(arun, ok, brun, acc);
+    if (wave < 4) mma_run_run<32>(arun, ok, brun, acc, rb);
     reduce_rows<4>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) {
         const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
         const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
@@ -1766,10 +1800,10 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
 // three kernel boundaries fewer per step and the two latency chains overlap.
 __global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
                                                       const float *__restrict__ dhf, float *__restrict__ dh3,
-                                                      float *__restrict__ grad, int B, int FC) {
+                                                      float *__restrict__ grad, int B, int FC, int rb) {
     __shared__ float red[8 * 16 * 64];
-    if ((int)blockIdx.x < n_dx) fc1_dx_body(blockIdx.x, red, params, h3, dhf, dh3, B, FC);
-    else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC);
+    if ((int)blockIdx.x < n_dx) fc1_dx_body(blockIdx.x, red, params, h3, dhf, dh3, B, FC, rb);
+    else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC, rb);
 }
 
 // TF ApplyAdam on four consecutive parameters (the one definition both Adam paths use)
@@ -1799,7 +1833,7 @@ __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan
 __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh3, const float *__restrict__ h2,
                                                         float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B,
-                                                        int n_adam, AdamSpan span, FbSampleRider rider) {
+                                                        int n_adam, AdamSpan span, FbSampleRider rider, int rb) {
     __shared__ float red[9 * 16 * 64];
     static_assert(sizeof(red) >= FB_SAMPLE_LDS_WORDS * 4, "the sampler borrows the reduction buffer");
     // fb_train_steps: random.sample for the NEXT train step rides as workgroup 0 (one wave of it): it needs the generator
@@ -1812,29 +1846,140 @@ __global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const 
     }
     const int n_conv = (int)gridDim.x - rid - n_adam;
     if (bid >= n_conv) adam_span_body(bid - n_conv, n_adam, span);
-    else if (bid < n_dx) conv3_dx_body(bid, red, params, dh3, h2, dh2, B);
+    else if (bid < n_dx) conv3_dx_body(bid, red, params, dh3, h2, dh2, B, rb);
     else {
         const int t = bid - n_dx;
-        conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride);
+        conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride, rb);
     }
 }
 
 __global__ __launch_bounds__(512) void conv2_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
                                                         const float *__restrict__ dh2, const float *__restrict__ p1,
-                                                        float *__restrict__ dp1, float *__restrict__ slabs, size_t slab_stride, int B) {
+                                                        float *__restrict__ dp1, float *__restrict__ slabs, size_t slab_stride, int B, int rb) {
     __shared__ float red[8 * 16 * 64];
-    if ((int)blockIdx.x < n_dx) conv2_dx_body(blockIdx.x, red, params, dh2, p1, dp1, B);
+    if ((int)blockIdx.x < n_dx) conv2_dx_body(blockIdx.x, red, params, dh2, p1, dp1, B, rb);
     else {
         const int t = blockIdx.x - n_dx;
-        conv_dw_body<2>(t % 34, t / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride);
+        conv_dw_body<2>(t % 34, t / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride, rb);
     }
 }
 
-__global__ __launch_bounds__(512) void conv1_dw_kernel(int nz, const uint8_t *__restrict__ states, const float *__restrict__ dp1,
-                                                       const uint8_t *__restrict__ amax, float *__restrict__ slabs,
-                                                       size_t slab_stride, int B) {
-    __shared__ float red[8 * 16 * 64];
-    conv_dw_body<1>(blockIdx.x % 9, blockIdx.x / 9, nz, red, B, nullptr, states, dp1, amax, slabs, slab_stride);
+// ---- conv1's weight gradient on the fp16 matrix cores, one sample per workgroup.
+// dW1[(ky, kx, ci)][co] = sum over output pixels of x[4 oy + ky - 2][4 ox + kx - 2][ci] * dY[oy][ox][co], dY = the pooled gradient routed to
+// each pool's maximum.  x is u8 -- exact in fp16 -- so with dY as two fp16 planes (split2x2) the products are exact and TWO
+// v_mfma_f32_32x32x16_f16 per 16 pixels and weight-row tile replace the eight fp32 MFMAs (4x the cycles each) of conv_dw_body<1>;
+// more important at these sizes, the operands come out of LDS at fixed offsets instead of through per-pixel address arithmetic
+// (that kernel spent ~750 vector instructions per 32 pixels and wave):
+//   * the sample's 80 x 80 x 4 bytes are copied once into a zero-padded LDS image [84][100][4] (conv1's SAME padding + slack for the
+//     padded pixel groups; rows of 416 bytes, pixel 0 at byte 16), so tap (ky, kx, ci) of 8 consecutive output pixels is 8 byte reads at base + 16 j;
+//   * output rows are cut into 3 groups of 8 pixels (20 = 8 + 8 + 4, the last group padded with dY = 0): a lane's 8 k-values never
+//     wrap a row; 30 MFMA steps per sample instead of 25;
+//   * dY's fragments are the same for all 8 weight-row tiles (ky): each wave builds those of 4 steps (pool routing, split, bias sum)
+//     into LDS, then wave ky walks all 30 steps.
+// One slab per sample: B slabs (conv_dw_body<1>: B x 400 / 256), summed by the Adam kernel / slab_fold_kernel as before.
+constexpr int DW1_IMG_W = 104, DW1_IMG_H = 84, DW1_IMG = DW1_IMG_H * DW1_IMG_W * 4;      // bytes; 4 zero pixels left of column 0 (16-byte rows), 2 zero rows above
+constexpr int DW1_STEPS = 30;
+
+// NSP workgroups per sample (each takes 30 / NSP consecutive steps and writes its own slab: small batches want more than B workgroups)
+template <int NSP>
+__global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restrict__ states, const float *__restrict__ dp1,
+                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, int B) {
+    constexpr int SW = DW1_STEPS / NSP, PU = (SW + 7) / 8;       // steps of this workgroup; fragment-building rounds per wave
+    __shared__ uint4 img4[DW1_IMG / 16];
+    __shared__ uint4 bfr[SW * 2 * 64];
+    __shared__ float bsum[8][32];
+    const int b = blockIdx.x / NSP, part = blockIdx.x - b * NSP, s0 = part * SW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, c = lane & 31;
+    uint8_t *img = reinterpret_cast<uint8_t *>(img4);
+    // ---- this wave's share of the dY fragments: local steps wave, wave + 8, .. ; lane (c, hl) holds pixels (group 2 st + hl, ox0 .. ox0 + 7) of
+    // channel c: 4 pooled pixels, each feeding the two window positions of its row.  All loads first.
+    float dv[PU][4];
+    int am[PU][4];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int ls = wave + 8 * u, g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int px = (ox0 >> 1) + q;
+            const bool ok = ls < SW && px < 10;
+            const uint32_t po = ((uint32_t)b * 100u + (uint32_t)(ok ? (oy >> 1) * 10 + px : 0)) * 32u + (uint32_t)c;
+            dv[u][q] = dp1[po]; am[u][q] = amax[po];
+        }
+    }
+    // ---- the padded image: zero everything, then the 80 rows of 320 bytes
+    uint4 px4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = tid + 512 * u; px4[u] = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600)[i < 1600 ? i : 0]; }
+    for (int i = tid; i < DW1_IMG / 16; i += 512) img4[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = tid + 512 * u, row = i / 20, col4 = i - row * 20;             // 20 uint4 (4 pixels x 4 frames each) per image row
+        if (i < 1600) *reinterpret_cast<uint4 *>(img + ((row + 2) * DW1_IMG_W + 4 + 4 * col4) * 4) = px4[u];
+    }
+    float bs = 0.f;
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int ls = wave + 8 * u, g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool ok = ls < SW && (ox0 >> 1) + q < 10;
+            const int pos = (oy & 1) * 2;
+            v[2 * q] = ok && am[u][q] == pos ? dv[u][q] : 0.f;
+            v[2 * q + 1] = ok && am[u][q] == pos + 1 ? dv[u][q] : 0.f;
+        }
+        uint4 fh, fl;
+        split2x2(v[0], v[1], fh.x, fl.x); split2x2(v[2], v[3], fh.y, fl.y); split2x2(v[4], v[5], fh.z, fl.z); split2x2(v[6], v[7], fh.w, fl.w);
+        if (ls < SW) { bfr[(ls * 2 + 0) * 64 + lane] = fh; bfr[(ls * 2 + 1) * 64 + lane] = fl; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) bs += v[q];
+    }
+    bs += __shfl_xor(bs, 32);
+    if (hl == 0) bsum[wave][c] = bs;
+    __syncthreads();
+    // ---- wave ky: weight rows (ky, kx, ci) = lane & 31; tap byte of pixel j of its group at tap0 + 16 j.  Image row 4 oy + ky (= input row
+    // 4 oy + ky - 2, two zero rows on top), column 4 ox + kx + 2 (= input column 4 ox + kx - 2, four zero pixels on the left).  The LDS
+    // reads of step st + 1 are issued before the MFMAs of step st (they return in order: the wait for step st leaves them in flight).
+    const int ky = wave, kx = c >> 2, ci = c & 3;
+    const uint8_t *tapk = img + (ky * DW1_IMG_W + kx + 2) * 4 + ci;
+    struct Ops { uint32_t x[8]; uint4 bh, bl; };
+    auto fetch = [&](int ls) {
+        const int g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+        const uint8_t *tap = tapk + ((4 * oy) * DW1_IMG_W + 4 * ox0) * 4;
+        Ops o;
+#pragma unroll
+        for (int jq = 0; jq < 8; jq++) o.x[jq] = tap[16 * jq];
+        o.bh = bfr[(ls * 2 + 0) * 64 + lane]; o.bl = bfr[(ls * 2 + 1) * 64 + lane];
+        return o;
+    };
+    f32x16 acc = {0}, acl = {0};
+    Ops cur = fetch(0);
+#pragma unroll
+    for (int ls = 0; ls < SW; ls++) {
+        Ops nxt = cur;
+        if (ls + 1 < SW) nxt = fetch(ls + 1);
+        uint4 A;
+        {
+            const f32x2 p0 = {(float)cur.x[0], (float)cur.x[1]}, p1 = {(float)cur.x[2], (float)cur.x[3]};      // u8 -> fp16 is exact
+            const f32x2 p2 = {(float)cur.x[4], (float)cur.x[5]}, p3 = {(float)cur.x[6], (float)cur.x[7]};
+            A.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, f16x2)); A.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, f16x2));
+            A.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, f16x2)); A.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, f16x2));
+        }
+        acc = mfma_h(A, cur.bh, acc);
+        acl = mfma_h(A, cur.bl, acl);
+        cur = nxt;
+    }
+    float *o = slabs + (size_t)blockIdx.x * slab_stride;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[OFF_W1 + (ky * 32 + drow(r, lane)) * 32 + c] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);
+    if (wave == 0 && hl == 0) {
+        float sum = bsum[0][c];
+#pragma unroll
+        for (int w = 1; w < 8; w++) sum += bsum[w][c];
+        o[OFF_B1 + c] = sum;
+    }
+    (void)B;
 }
 
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
@@ -1948,6 +2093,7 @@ struct fb_qnet {
     uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
     uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [3][S*3200], conv3 out [3][S*1600] bf16
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
+    int nsplit_train;                // the same for training (fb_qnet_set_train_dtype): 1 = bf16 operands, fp32 accumulation + master weights
     bool adam_ticked;                // host-side hint only (eager calls): the last train step left a tick pending for fb_qnet_apply_adam;
                                      // the truth is AdamDev::ticks / applies on the device
     AdamDev *adam;
@@ -1986,12 +2132,12 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->params[0], nb); alloc((void **)&h->params[1], nb);
     alloc((void **)&h->adam_m, nb); alloc((void **)&h->adam_v, nb); alloc((void **)&h->grad, nb);
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
-    if ((max_batch * 400 + 255) / 256 > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)FOLD * h->zmax * CONV1_PARAMS);
+    if (max_batch > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)FOLD * h->zmax * CONV1_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
     const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)(200 + 4) * 3 * fc_width) * sizeof(uint4);   // + one chunk: fc1_sp_kernel over-reads
     alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
-    h->nsplit = 3;
+    h->nsplit = 3; h->nsplit_train = 3;
     alloc((void **)&h->zeros, 256);
     alloc((void **)&h->a1s, S * 3200 * 6); alloc((void **)&h->a3s, S * 1600 * 6 + 256);
     alloc((void **)&h->p1, S * 3200 * 4); alloc((void **)&h->amax, S * 3200);
@@ -2045,6 +2191,12 @@ extern "C" int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float bet
 extern "C" int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype) {
     FB_REQUIRE(h && (dtype == FB_DTYPE_F32 || dtype == FB_DTYPE_BF16), "fb_qnet_set_inference_dtype: dtype must be FB_DTYPE_F32 or FB_DTYPE_BF16");
     h->nsplit = dtype == FB_DTYPE_BF16 ? 1 : 3;
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_set_train_dtype(fb_qnet_t h, int dtype) {
+    FB_REQUIRE(h && (dtype == FB_DTYPE_F32 || dtype == FB_DTYPE_BF16), "fb_qnet_set_train_dtype: dtype must be FB_DTYPE_F32 or FB_DTYPE_BF16");
+    h->nsplit_train = dtype == FB_DTYPE_BF16 ? 1 : 3;
     return FB_OK;
 }
 
@@ -2129,47 +2281,56 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
     // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
     const bool big = maxc >= 256;
-    // forward only (no activations kept for a backward) and big: the split-bf16 path
-    const bool sp = big && !p.train && p.ns == 1;
-    const int t1 = (maxc * 100 + 7) / 8, t23 = (maxc * 25 + 31) / 32;
+    // >= 256 states per slice: the LDS-staged two-plane-fp16 kernels (conv1_sp / conv23_sp / fc1_sp).  Forward-only plans take
+    // them with one slice; TRAINING plans run them in passes, one per run of consecutive slices that go through the same net
+    // (DQN: s and s' in one pass; Nature / PER: s online, s' target; Double: s, s' online + s' target), with fp32 side outputs
+    // (pooled conv1 + pool positions, conv2, conv3) for the backward kernels.  nsp: 3 = fp32-equivalent, 1 = bf16 operands.
+    const bool sp = big;
+    const int nsp = p.train ? h->nsplit_train : h->nsplit;
+    const int t23 = (maxc * 25 + 31) / 32, t1 = (maxc * 100 + 7) / 8;
     const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
-    // stale split weights: refreshed by the leading workgroups of the conv1 launch (or by a launch of their own when
-    // only a later kernel of the plan is requested)
-    // (decided on the device from AdamDev::pver / wver; a single profiled kernel never re-splits: fb_qnet_profile_kernel
-    // brings wsp up to date once, in front of its loop)
-    const unsigned *pver = sp && only < 0 ? &h->adam->pver[p.which] : nullptr;
-    unsigned *wver = sp && only < 0 ? &h->adam->wver[p.which] : nullptr;
-    FB_K(K_CONV1) {
-        const dim3 g1((t1 + 3) / 4, 1, p.ns);
-        if (sp) {
-            // persistent: one 12-wave workgroup per CU, the waves stride over the tiles
-            const int gsp = min(256, (t1 + C1_WAVES - 1) / C1_WAVES);
-            if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, pver, (const unsigned *)wver);
-            else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, p.sl.s[0], (const uint8_t *)h->zeros, h->a1s, pl1, h->nsplit, h->wsp[p.which], h->FC, pver, (const unsigned *)wver);
-        } else if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
-        else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
-    }
     const int stot = 3 * h->max_batch;
     if (sp) {
-        C23Args c23{h->a1s, pl1, h->wsp[p.which] + WSP_W2, p.sl.s[0].params + OFF_B2, p.sl.s[0].params + OFF_B3, h->a3s, pl2, maxc, pver, wver};
-        Fc1Args af{h->a3s, pl2, h->zeros, h->wsp[p.which] + WSP_WF1, h->hf, stot, maxc, h->FC};
-        const dim3 gc((maxc + 4) / 5), gf(((maxc + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
-        if (h->nsplit == 3) {
-            FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
-            FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
-        } else {
-            FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(256), 0, st, c23);
-            FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
+        for (int z0 = 0; z0 < p.ns;) {
+            int z1 = z0 + 1;
+            while (z1 < p.ns && p.sl.s[z1].params == p.sl.s[z0].params && p.sl.s[z1].count == p.sl.s[z0].count && p.sl.s[z1].s_off == p.sl.s[z1 - 1].s_off + p.sl.s[z1 - 1].count) z1++;
+            const Slice s0 = p.sl.s[z0];
+            const int which = s0.params == h->params[1] ? 1 : 0, row0 = s0.s_off, rows = s0.count * (z1 - z0);
+            // stale split weights are refreshed by the leading workgroups of the conv1 launch, decided on the device from
+            // AdamDev::pver / wver (a single profiled kernel never re-splits: fb_qnet_profile_kernel brings wsp up to date once)
+            const unsigned *pver = only < 0 ? &h->adam->pver[which] : nullptr;
+            unsigned *wver = only < 0 ? &h->adam->wver[which] : nullptr;
+            Slice sl = s0;
+            sl.count = rows;
+            C1Side side;
+            memset(&side, 0, sizeof(side));
+            if (z1 - z0 > 1) { side.per = s0.count; side.st1 = p.sl.s[z0 + 1].states; side.st2 = z1 - z0 > 2 ? p.sl.s[z0 + 2].states : p.sl.s[z0 + 1].states; }
+            if (p.train) { side.p1 = h->p1; side.amax = h->amax; }
+            const int t1p = (rows * 100 + 7) / 8, gsp = min(256, (t1p + C1_WAVES - 1) / C1_WAVES);      // one 12-wave workgroup per CU, the waves stride over the tiles
+            FB_K(K_CONV1) {
+                if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
+                else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
+            }
+            C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver,
+                        p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr};
+            Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC};
+            const dim3 gc((rows + 4) / 5), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
+            if (nsp == 3) {
+                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
+                FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
+            } else {
+                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(256), 0, st, c23);
+                FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
+            }
+            z0 = z1;
         }
+    } else FB_K(K_CONV1) {
+        const dim3 g1((t1 + 3) / 4, 1, p.ns);
+        if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
+        else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
-    if (!sp) FB_K(K_CONV2) {
-        if (big) hipLaunchKernelGGL(conv2_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->p1, h->h2);
-        else hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
-    }
-    if (!sp) FB_K(K_CONV3) {
-        if (big) hipLaunchKernelGGL(conv3_big_kernel, dim3((t23 + 3) / 4, 2, p.ns), dim3(256), 0, st, p.sl, h->h2, h->h3);
-        else hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
-    }
+    if (!sp) FB_K(K_CONV2) hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
+    if (!sp) FB_K(K_CONV3) hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
     // small batches: the whole K per workgroup (fc1_fk_kernel), which lets training skip the head and loss launches
     const bool fk = !sp && !big;
     if (fk) FB_K(K_FC1) {
@@ -2178,15 +2339,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         fa.dueling = h->arch == FB_ARCH_DUELING; fa.stot = stot; fa.off = h->off;
         hipLaunchKernelGGL(fc1_fk_kernel, dim3((maxc + 15) / 16, h->FC / 16, p.ns), dim3(512), 0, st, fa);
     }
-    if (!sp && !fk) FB_K(K_FC1) {
-        if (big) hipLaunchKernelGGL(fc1_big_kernel, dim3(((maxc + 31) / 32 + 3) / 4, h->FC / 32, p.ns * FC1_BIG_KS), dim3(256), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
-        else hipLaunchKernelGGL(fc1_kernel, dim3((maxc + 31) / 32, h->FC / 32, p.ns * FC1_KS), dim3(512), 0, st, p.sl, h->h3, h->hf, h->FC, stot);
-    }
     if (!(fk && p.train)) FB_K(K_HEAD) {            // (small-batch training gets Q from fc1_fk_kernel's shares instead)
         HeadArgs H;
         H.sl = p.sl; H.nslices = p.ns;
         HeadCore &C = H.c;
-        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : big ? FC1_BIG_KS : 1; C.q = h->q; C.FC = h->FC; C.A = h->A;
+        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : 1; C.q = h->q; C.FC = h->FC; C.A = h->A;
         C.dueling = h->arch == FB_ARCH_DUELING; C.off = h->off; C.actions = p.actions; C.epsilon = p.epsilon;
         C.seed_lo = (uint32_t)p.seed; C.seed_hi = (uint32_t)(p.seed >> 32);
         C.step_lo = (uint32_t)p.step; C.step_hi = (uint32_t)(p.step >> 32);
@@ -2194,12 +2351,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         else hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
     }
     if (p.train) {
-        const int B = p.B, FC = h->FC;
+        const int B = p.B, FC = h->FC, rbt = h->nsplit_train == 1;       // bf16 training: operands rounded to bf16
         float *G = p.G;
         if (!fk) FB_K(K_LOSS) {
             LossArgs L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
-            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = big ? FC1_BIG_KS : FC1_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;
+            L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = FC1_SP_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;      // (only large batches come here: fc1_sp_kernel's 4 K slices)
             L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             // data-parallel path: the loss kernel advances the Adam step counter as well (once per fb_qnet_apply_adam), so the
             // apply needs no launch of its own for it
@@ -2222,9 +2379,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.hf = h->hf; L.qpart = h->qpart; L.h3 = h->h3; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw; L.gamma = p.gamma;
             L.grad = G; L.dh3 = h->dh3; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
-            L.adam = h->adam; L.tick = p.tick;
+            L.adam = h->adam; L.tick = p.tick; L.rb = rbt;
             hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7), dim3(512), 0, st, L);
-        } } else FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+        } } else FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, rbt);
         const int ndx3 = ((B * 25 + 31) / 32) * 2;
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
@@ -2234,19 +2391,25 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
         FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam + (srider.k ? 1 : 0)), dim3(576), 0, st, ndx3, z3,
-                                             h->params[0], h->dh3, h->h2, h->dh2, h->slabs, ss, B, n_adam, span, srider);
+                                             h->params[0], h->dh3, h->h2, h->dh2, h->slabs, ss, B, n_adam, span, srider, rbt);
         const int ndx2 = ((B * 25 + 31) / 32) * 4;
         FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
-                                             h->dp1, h->slabs, ss, B);
-        int zsub = (B * 400 + 255) / 256;                      // one 32-pixel chunk per wave when there is room for it
-        if (zsub > FOLD * h->zmax) zsub = FOLD * h->zmax;
-        if (zsub > h->zmax) {
-            z1 = (zsub + FOLD - 1) / FOLD;
+                                             h->dp1, h->slabs, ss, B, rbt);
+        // conv1's weight gradient: one slab per workgroup of conv1_dw2_kernel -- two workgroups per sample while that stays within zmax
+        // slabs (small batches need the parallelism), one per sample beyond; more than zmax samples go through 4 : 1 folding
+        if (B > h->zmax) {
+            z1 = (B + FOLD - 1) / FOLD;
             FB_K(K_CONV1_DW) {
-                hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * zsub), dim3(512), 0, st, zsub, p.s, h->dp1, h->amax, h->slabs1, (size_t)CONV1_PARAMS, B);
-                hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, zsub, h->slabs, ss);
+                hipLaunchKernelGGL(conv1_dw2_kernel<1>, dim3(B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs1, (size_t)CONV1_PARAMS, B);
+                hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
             }
-        } else FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw_kernel, dim3(9 * z1), dim3(512), 0, st, z1, p.s, h->dp1, h->amax, h->slabs, ss, B);
+        } else if (2 * B <= h->zmax) {
+            z1 = 2 * B;
+            FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw2_kernel<2>, dim3(2 * B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs, ss, B);
+        } else {
+            z1 = B;
+            FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw2_kernel<1>, dim3(B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs, ss, B);
+        }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
@@ -2365,6 +2528,7 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
     if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]};               // BrainDQN.py:205 (same net)
     else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B, h->w1s[1]}; p.ns = 3; }
     else p.sl.s[1] = Slice{h->params[1], s2, B, B, h->w1s[1]};                                   // target net
+    p.sl.rb = h->nsplit_train == 1;
     p.train = true; p.algo = algo; p.B = B; p.s = s; p.a = a; p.r = r; p.t = t; p.isw = isw; p.gamma = gamma;
     p.loss = loss; p.abs_err = abs_err; p.y = q_target;
     p.G = flat_grad ? flat_grad : h->grad;
@@ -2421,6 +2585,6 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
 extern "C" const char *fb_qnet_kernel_name(int kernel) {
     static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv2_kernel", "conv3_kernel", "fc1_kernel", "head_kernel",
                                          "loss_head_kernel", "fc1_bwd_kernel", "conv3_bwd_kernel", "conv2_bwd_kernel",
-                                         "conv1_dw_kernel", "slab_reduce_kernel", "adam_kernel"};
+                                         "conv1_dw2_kernel", "slab_reduce_kernel", "adam_kernel"};
     return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }

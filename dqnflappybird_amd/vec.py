@@ -300,6 +300,10 @@ class QNet:
         L.check(L.lib().fb_qnet_set_inference_dtype(self.h, {"f32": L.DTYPE_F32, "bf16": L.DTYPE_BF16}[dtype]),
                 "fb_qnet_set_inference_dtype")
 
+    def set_train_dtype(self, dtype="f32"):
+        """'f32' (default) or 'bf16': arithmetic of train_step (bf16 operands, fp32 accumulation, fp32 master weights + Adam)."""
+        L.check(L.lib().fb_qnet_set_train_dtype(self.h, {"f32": L.DTYPE_F32, "bf16": L.DTYPE_BF16}[dtype]), "fb_qnet_set_train_dtype")
+
     def adam_state(self):
         m = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
         v = torch.empty_like(m)

@@ -122,6 +122,12 @@ class VecBrain:
         self.timeStep += 1
         self.onlineTimeStep += 1
 
+    def set_dtype(self, dtype="f32"):
+        """'bf16' = BASELINE.json configs[2]'s arithmetic for acting AND training (fp32 master weights / Adam); 'f32' = default."""
+        self.net.set_inference_dtype(dtype)
+        self.net.set_train_dtype(dtype)
+        self.dtype = dtype
+
     # ------------------------------------------------------------------ checkpoint / resume of the WHOLE loop
     def save(self, path):
         """Everything the device-resident loop needs to continue bit for bit: both nets + Adam slots (what the reference saves,

@@ -230,6 +230,12 @@ int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float e
 #define FB_DTYPE_F32 0
 #define FB_DTYPE_BF16 1
 int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype);
+/* Arithmetic of fb_qnet_train_step (BASELINE.json configs[2]: "bf16"):
+ *   FB_DTYPE_F32  (default) fp32: small batches on the fp32-input matrix instruction, >= 256 states per slice on two-plane fp16
+ *   FB_DTYPE_BF16 bf16 training: every GEMM operand (activations, weights, incoming gradients; conv1's u8 input is exact anyway)
+ *                 is rounded to bf16, products accumulate in fp32, the master weights and both Adam slots stay fp32.  Gradients
+ *                 then agree with fp32 ones to ~1 % per tensor (tests/test_gpu_configs.py states the bound). */
+int fb_qnet_set_train_dtype(fb_qnet_t h, int dtype);
 /* QValue.eval: states u8[B,80,80,4] -> q f32[B,A] */
 int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream);
 /* getAction for N envs: forward + epsilon-greedy (Philox stream 1, counter = step).
