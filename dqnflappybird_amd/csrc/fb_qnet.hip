@@ -285,9 +285,48 @@ __device__ __forceinline__ uint4 nib_lut_entry(unsigned t) {   // byte t = 2 pix
 // last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
 // bf16x8 operand comes out of a 256-entry LDS table with one ds_read_b128 -- no u8 -> bf16 conversion, and
 // the 25.6 KB/env currentState expansion (its own launch before) disappears.
+constexpr int WSP_W2 = 0, WSP_W3 = 64 * 3 * 64, WSP_WF1 = WSP_W3 + 72 * 3 * 64;     // uint4 offsets inside wsp
+
+__device__ __forceinline__ void wsplit_item(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, int id) {
+    const float *W; uint4 *out; int N;
+    if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
+    else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
+    else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
+    const int k8 = id / N, col = id - k8 * N;
+    // plane 0: fp16 h, plane 1: fp16 l (split2x2), plane 2: the weight rounded to bf16 (bf16 inference mode, FB_DTYPE_BF16)
+    uint32_t hi[4], lo[4], bh[4], m_, l_;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float w0 = W[(size_t)(k8 * 8 + 2 * e) * N + col], w1 = W[(size_t)(k8 * 8 + 2 * e + 1) * N + col];
+        split2x2(w0, w1, hi[e], lo[e]);
+        split3x2(w0, w1, bh[e], m_, l_);
+    }
+    uint4 *o = out + (size_t)k8 * 3 * N + col;
+    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o[N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    o[2 * N] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
+}
+
+// stand-alone re-split (the acting forward normally does it inside its conv1 launch): only when the versions differ
+__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, const unsigned *__restrict__ pver,
+                              const unsigned *__restrict__ wver) {
+    if (*pver == *wver) return;
+    wsplit_item(params, wsp, FC, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// (the launch also re-splits W_conv2 / W_conv3 of a net whose parameters changed since its planes were built -- conv23_t_kernel, the
+// next launch, reads them -- a few items per thread in front of the tile work, decided on the device like conv1_sp_kernel does)
+struct SplitJob { const float *params[2]; uint4 *wsp[2]; const unsigned *pver[2], *wverc[2]; int FC; };
+
 template <bool NIB>
-__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax) {
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__restrict__ p1, uint8_t *__restrict__ amax, SplitJob job) {
     __shared__ uint4 lut[NIB ? 256 : 1];
+    if (blockIdx.z == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+            if (job.pver[n] && *job.pver[n] != *job.wverc[n])
+                for (int id = blockIdx.x * 256 + threadIdx.x; id < 64 * 64 + 72 * 64; id += gridDim.x * 256) wsplit_item(job.params[n], job.wsp[n], job.FC, id);
+    }
     if (NIB) {
         lut[threadIdx.x] = nib_lut_entry(threadIdx.x);       // element j = 4*px + f  <->  bit j of the byte
         __syncthreads();
@@ -485,35 +524,6 @@ __global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__
 // Activations travel between the layers as three bf16 planes [plane][row][channel]; the weights are
 // re-split (wsplit_kernel) whenever the parameters changed: wsp[k/8][plane][N] x 8 bf16 (16 B).
 // NS = 3: the fp32-equivalent path; NS = 1 uses the hi planes only = plain bf16 inference.
-constexpr int WSP_W2 = 0, WSP_W3 = 64 * 3 * 64, WSP_WF1 = WSP_W3 + 72 * 3 * 64;     // uint4 offsets inside wsp
-
-__device__ __forceinline__ void wsplit_item(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, int id) {
-    const float *W; uint4 *out; int N;
-    if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
-    else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
-    else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
-    const int k8 = id / N, col = id - k8 * N;
-    // plane 0: fp16 h, plane 1: fp16 l (split2x2), plane 2: the weight rounded to bf16 (bf16 inference mode, FB_DTYPE_BF16)
-    uint32_t hi[4], lo[4], bh[4], m_, l_;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const float w0 = W[(size_t)(k8 * 8 + 2 * e) * N + col], w1 = W[(size_t)(k8 * 8 + 2 * e + 1) * N + col];
-        split2x2(w0, w1, hi[e], lo[e]);
-        split3x2(w0, w1, bh[e], m_, l_);
-    }
-    uint4 *o = out + (size_t)k8 * 3 * N + col;
-    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    o[N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    o[2 * N] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
-}
-
-// stand-alone re-split (the acting forward normally does it inside its conv1 launch): only when the versions differ
-__global__ void wsplit_kernel(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, const unsigned *__restrict__ pver,
-                              const unsigned *__restrict__ wver) {
-    if (*pver == *wver) return;
-    wsplit_item(params, wsp, FC, blockIdx.x * blockDim.x + threadIdx.x);
-}
-
 // conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
 // L1/L2 traffic at 1024 states); here a workgroup parks them in LDS once and its waves walk over tiles, the
 // next tile's input bytes in flight while the current one is in the MFMAs.  The vector ALU is the scarce unit here
@@ -677,6 +687,7 @@ struct C23Args {
     uint16_t *a3s; size_t pl3;               // conv3 output planes [3][n*25][64]
     int n;
     const unsigned *pver; unsigned *wver;    // whole forward plans: the conv1 launch in front re-split the weights if these differed
+    unsigned *wverc;                         // (the conv part's own version word, see AdamDev)
     float *h2o, *h3o;                        // training: fp32 copies of conv2's / conv3's output rows [n*25][64] for the backward pass, or NULL
 };
 
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     __shared__ uint4 smem[RING + 3 * RSZ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
     const int s0 = blockIdx.x * 5, ml = wave * 32 + j;
-    if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) *a.wver = *a.pver;
+    if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) { *a.wver = *a.pver; *a.wverc = *a.pver; }
     const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
     const bool rowok = ml < 125;
     int nloc = a.n - s0; if (nloc > 5) nloc = 5;
@@ -865,6 +876,126 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     });
 }
 
+// conv2 + conv3 for SMALL batches (training, and any forward below 256 states): one workgroup per state, the same two-plane fp16
+// arithmetic as conv23_sp_kernel (three MFMAs per fp32 product; NS = 1: one bf16 plane).  The two stand-alone fp32-MFMA kernels
+// (conv2_kernel, conv3_kernel) were two launches of ~6.5 + 7.5 us whose matrix work is under a microsecond: what they wait for is
+// the launch, a cold read of what the previous launch wrote, a 32-deep chain of 64-cycle fp32 MFMAs and an LDS reduction -- twice.
+// Here conv1's pooled output of ONE state (12.8 KB fp32) is split into planes in LDS once, conv2's output never leaves the CU, and
+// the 17 weight chunks of 64 k (8 for conv2's 16 taps x 32 channels, 9 for conv3's taps x 64 channels) stream through a 3-slot LDS
+// ring.  8 waves = 2 channel tiles x 4 k-steps of a chunk; the four k partial sums per tile are added through LDS in a fixed order.
+// fp32 side outputs h2 / h3 feed the backward kernels and fc1.  Operands swapped as in conv23_sp_kernel (D = W^T x A^T): a lane owns
+// 4 consecutive channels of one pixel per register quad.
+struct C23T {
+    Slices sl;
+    const float *p1; float *h2, *h3;
+    const uint4 *w[3];                       // per slice: split weights of its net (wsp + WSP_W2)
+    const unsigned *pver[2]; unsigned *wverc[2];     // the launch in front re-split W_conv2 / W_conv3 of a stale net: record it
+};
+
+template <int NS>
+__global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
+    constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
+    constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RING = ZOFF + 16, RSZ = 8 * NPL * 64, RED = RING + 3 * RSZ;
+    constexpr int NQ = RSZ / 512;                    // uint4 per thread and chunk
+    __shared__ uint4 smem[RED + 2048];
+    float *red = reinterpret_cast<float *>(smem + RED);
+    const Slice s = a.sl.s[blockIdx.y];
+    if ((int)blockIdx.x >= s.count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = lane & 31, ct = wave & 1, kq = wave >> 1;
+    const size_t row = (size_t)s.s_off + blockIdx.x;
+    const uint4 *w = a.w[blockIdx.y];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 && a.wverc[tid]) *a.wverc[tid] = *a.pver[tid];
+    struct BSt { uint4 v0, v1; };
+    auto srcB = [&](int c, int q) {
+        const int e = tid + 512 * q, k8l = e / (64 * NPL), pl = (e >> 6) % NPL;
+        return w + ((size_t)(8 * c + k8l) * 3 + P0 + pl) * 64 + (e & 63);
+    };
+    auto loadB = [&](int c) { BSt r; r.v0 = *srcB(c, 0); r.v1 = NQ == 2 ? *srcB(c, NQ - 1) : r.v0; return r; };
+    auto storeB = [&](int slot, const BSt r) { smem[RING + slot * RSZ + tid] = r.v0; if (NQ == 2) smem[RING + slot * RSZ + 512 + tid] = r.v1; };
+    BSt b0 = loadB(0), b1 = loadB(1);
+    {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
+        float4 t[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) { const int i = tid + 512 * r; t[r] = reinterpret_cast<const float4 *>(a.p1 + row * 3200)[i < 800 ? i : 0]; }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = tid + 512 * r, pix = i >> 3, q8 = i & 7;
+            uint32_t h0, l0, h1, l1, m_;
+            if constexpr (NS == 3) { split2x2(t[r].x, t[r].y, h0, l0); split2x2(t[r].z, t[r].w, h1, l1); }
+            else { split3x2(t[r].x, t[r].y, h0, m_, l0); split3x2(t[r].z, t[r].w, h1, m_, l1); }
+            if (i < 800) {
+                uint2 *d = reinterpret_cast<uint2 *>(smem + pix * 4 + (((q8 >> 1) + (pix >> 2)) & 3)) + (q8 & 1);
+                d[0] = make_uint2(h0, h1);
+                if (NS == 3) d[2 * IN_P] = make_uint2(l0, l1);          // plane 1: IN_P uint4 further
+            }
+        }
+        if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    storeB(0, b0); storeB(1, b1);
+    BSt bn = loadB(2);
+    __syncthreads();
+    const int oy = j / 5, ox = j - oy * 5;
+    const bool rowok = j < 25;
+    f32x16 acc = {0}, acl = {0};
+    // the four k partial sums of each channel tile, added in k order; wave (ct', q) finishes registers 4q .. 4q + 3 of tile ct': channels
+    // ct' * 32 + 8 q + 4 hl .. + 3 of pixel j
+    auto finish = [&](const float *__restrict__ bias, float *__restrict__ out, bool planes) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[((kq * 2 + ct) * 16 + r) * 64 + lane] = NS == 3 ? fmaf(acl[r], F16_LO_UNSCALE, acc[r]) : acc[r];
+        __syncthreads();
+        const int ctp = wave & 1, q = wave >> 1;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[e] = red[((0 * 2 + ctp) * 16 + 4 * q + e) * 64 + lane];
+#pragma unroll
+            for (int k = 1; k < 4; k++) v[e] += red[((k * 2 + ctp) * 16 + 4 * q + e) * 64 + lane];
+        }
+        const int ch = ctp * 32 + 8 * q + 4 * hl;
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + ch);
+        v[0] = fmaxf(v[0] + bv.x, 0.f); v[1] = fmaxf(v[1] + bv.y, 0.f); v[2] = fmaxf(v[2] + bv.z, 0.f); v[3] = fmaxf(v[3] + bv.w, 0.f);
+        if (rowok) *reinterpret_cast<float4 *>(out + (row * 25 + j) * 64 + ch) = make_float4(v[0], v[1], v[2], v[3]);
+        if (planes && rowok) {
+            uint32_t h0, l0, h1, l1, m_;
+            if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
+            else { split3x2(v[0], v[1], h0, m_, l0); split3x2(v[2], v[3], h1, m_, l1); }
+            uint2 *d = reinterpret_cast<uint2 *>(smem + C2O + j * 8 + ((ctp * 4 + q) ^ ((j >> 1) & 7))) + hl;
+            d[0] = make_uint2(h0, h1);
+            if (NS == 3) d[2 * C2_P] = make_uint2(l0, l1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[r] = 0.f; acl[r] = 0.f; }
+    };
+#pragma unroll
+    for (int c = 0; c < 17; c++) {
+        // this wave's k-step of chunk c: 16 k = two 8-k pieces (lane halves)
+        int aidx[2];
+        if (c < 8) {                                                     // conv2: chunk = taps 2c, 2c + 1 x 32 channels
+            const int tap = 2 * c + (kq >> 1), iy = 2 * oy + (tap >> 2) - 1, ix = 2 * ox + (tap & 3) - 1, pix = iy * 10 + ix;
+            const bool ok = rowok && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) aidx[p] = ok ? p * IN_P + pix * 4 + ((((kq & 1) * 2 + hl) + (pix >> 2)) & 3) : ZOFF;
+        } else {                                                         // conv3: chunk = tap c - 8 x 64 channels
+            const int tap = c - 8, ky = tap / 3, iy = oy + ky - 1, ix = ox + (tap - 3 * ky) - 1, pix = iy * 5 + ix;
+            const bool ok = rowok && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) aidx[p] = ok ? C2O + p * C2_P + pix * 8 + ((2 * kq + hl) ^ ((pix >> 1) & 7)) : ZOFF;
+        }
+        uint4 W[NPL], A[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; p++) { W[p] = smem[RING + (c % 3) * RSZ + ((2 * kq + hl) * NPL + p) * 64 + ct * 32 + j]; A[p] = smem[aidx[p]]; }
+        if constexpr (NS == 3) {
+            acl = mfma_h(W[0], A[1], acl);
+            acl = mfma_h(W[1], A[0], acl);
+            acc = mfma_h(W[0], A[0], acc);
+        } else acc = mfma_b(W[0], A[0], acc);
+        if (c + 2 < 17) { storeB((c + 2) % 3, bn); if (c + 3 < 17) bn = loadB(c + 3); }
+        if (c == 7) finish(s.params + OFF_B2, a.h2, true);               // conv2 done: its output becomes conv3's LDS image
+        __syncthreads();
+    }
+    finish(s.params + OFF_B3, a.h3, false);
+}
+
 // fc1 of that path: hfp[ks] = A[M x 1600] x W[1600 x N] over a quarter of K.  One workgroup = 128 rows x 64 columns x
 // 12 or 13 chunks of 32 k (grid z = 4 slices: exactly 256 workgroups at 1024 states and N = 512).  Both operands go
 // through LDS: the activation chunk is fetched as 64-byte row segments (4 lanes per row, not one 16-byte fragment
@@ -1017,8 +1148,10 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
 //                     tick has been consumed by an Adam update (ticks == applies); the Adam kernel marks it consumed
 //   pver / wver       version of the parameters of net 0 / 1 (bumped by whatever writes them: Adam, init, load, target sync) and
 //                     the version the bf16 hi/mid/lo split of W_conv2 / W_conv3 / W_fc1 (wsp) was built from; the acting forward
-//                     compares the two ON THE DEVICE and re-splits when they differ
-struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; int ticks, applies; unsigned pver[2], wver[2]; };
+//                     compares the two ON THE DEVICE and re-splits when they differ.  wverc: the same for the W_conv2 / W_conv3 part
+//                     alone, which is all the small-batch conv2+conv3 kernel needs (conv23_t_kernel; a train-only loop re-splits 70 K
+//                     weights per step, not 890 K)
+struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; int ticks, applies; unsigned pver[2], wver[2], wverc[2]; };
 
 struct LossArgs {
     int algo, B, FC, A, dueling;
@@ -1189,7 +1322,7 @@ __global__ void adam_tick_kernel(AdamDev *ad) {
     ad->ticks += 1;
 }
 __global__ void bump_pver_kernel(AdamDev *ad, int which) { ad->pver[which] += 1; }
-__global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad->pver[which]; }
+__global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad->pver[which]; ad->wverc[which] = ad->pver[which]; }
 
 // ================================================================== fc1 + loss, small batches (training, < 256 states)
 // fc1 with the WHOLE reduction in one workgroup.  fc1_kernel above splits K = 1600 over 5 workgroups, which leaves five partial
@@ -2311,7 +2444,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
                 else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
             }
-            C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver,
+            C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver, only < 0 ? &h->adam->wverc[which] : nullptr,
                         p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr};
             Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC};
             const dim3 gc((rows + 4) / 5), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
@@ -2324,13 +2457,34 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             }
             z0 = z1;
         }
-    } else FB_K(K_CONV1) {
-        const dim3 g1((t1 + 3) / 4, 1, p.ns);
-        if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
-        else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax);
     }
-    if (!sp) FB_K(K_CONV2) hipLaunchKernelGGL(conv2_kernel, dim3(t23, 2, p.ns), dim3(512), 0, st, p.sl, h->p1, h->h2);
-    if (!sp) FB_K(K_CONV3) hipLaunchKernelGGL(conv3_kernel, dim3(t23, 2, p.ns), dim3(576), 0, st, p.sl, h->h2, h->h3);
+    // small batches: conv2 + conv3 in one launch on the split planes (conv23_t_kernel); the conv1 launch in front re-splits the conv
+    // weights of every net of the plan whose parameters moved (decided on the device), the conv2+conv3 launch records it
+    SplitJob job;
+    C23T c23t;
+    memset(&job, 0, sizeof(job)); memset(&c23t, 0, sizeof(c23t));
+    if (!sp) {
+        job.FC = h->FC;
+        c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3;
+        for (int z = 0; z < p.ns; z++) {
+            const int which = p.sl.s[z].params == h->params[1] ? 1 : 0;
+            c23t.w[z] = h->wsp[which] + WSP_W2;
+            if (only < 0) {
+                job.params[which] = h->params[which]; job.wsp[which] = h->wsp[which];
+                job.pver[which] = &h->adam->pver[which]; job.wverc[which] = &h->adam->wverc[which];
+                c23t.pver[which] = &h->adam->pver[which]; c23t.wverc[which] = &h->adam->wverc[which];
+            }
+        }
+    }
+    if (!sp) FB_K(K_CONV1) {
+        const dim3 g1((t1 + 3) / 4, 1, p.ns);
+        if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
+        else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
+    }
+    if (!sp) FB_K(K_CONV2) {                         // (conv3 rides in the same launch)
+        if (nsp == 3) hipLaunchKernelGGL(conv23_t_kernel<3>, dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        else hipLaunchKernelGGL(conv23_t_kernel<1>, dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+    }
     // small batches: the whole K per workgroup (fc1_fk_kernel), which lets training skip the head and loss launches
     const bool fk = !sp && !big;
     if (fk) FB_K(K_FC1) {
@@ -2572,11 +2726,13 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
     } else rc = train_plan(h, algo, B, s, a, r, s2, t, nullptr, 0.99, loss, nullptr, nullptr, nullptr, &p);
     if (rc != FB_OK) return rc;
     p.tick = false;
-    if (algo < 0 && B >= 256) {                  // the split-bf16 path: bring wsp up to date once, outside the timed launches
+    {                                            // bring both nets' split planes up to date once, outside the timed launches
         const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
-        hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, fb_stream(stream), h->params[0], h->wsp[0], h->FC,
-                           (const unsigned *)&h->adam->pver[0], (const unsigned *)&h->adam->wver[0]);
-        hipLaunchKernelGGL(mark_split_kernel, dim3(1), dim3(1), 0, fb_stream(stream), h->adam, 0);
+        for (int n = 0; n < 2; n++) {
+            hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, fb_stream(stream), h->params[n], h->wsp[n], h->FC,
+                               (const unsigned *)&h->adam->pver[n], (const unsigned *)&h->adam->wver[n]);
+            hipLaunchKernelGGL(mark_split_kernel, dim3(1), dim3(1), 0, fb_stream(stream), h->adam, n);
+        }
     }
     for (int i = 0; i < reps; i++) { rc = run_plan(h, p, kernel, fb_stream(stream)); if (rc != FB_OK) return rc; }
     return FB_OK;
