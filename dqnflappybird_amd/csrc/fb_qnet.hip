@@ -140,44 +140,6 @@ __device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool
 }
 
 // ================================================================== forward
-// conv2 4x4x32->64 stride 2 SAME(1,1) + bias + relu; 8 waves = 16 kernel cells / 2
-__global__ __launch_bounds__(512) void conv2_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
-    __shared__ float red[8 * 16 * 64];
-    const Slice s = sl.s[blockIdx.z];
-    const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int ky = wave >> 1, kx = 2 * (wave & 1) + hl;
-    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
-    const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
-    const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
-    const float *arun = p1 + (((size_t)(s.s_off + (ok ? b : 0)) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
-    const float *bcol = s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j;
-    f32x16 acc = {0};
-    mma_run_col<32>(arun, ok, bcol, 64, acc, sl.rb);
-    const float bias = s.params[OFF_B2 + n0 + j];
-    reduce_rows<8>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
-}
-
-// conv3 3x3x64->64 stride 1 SAME(1,1) + bias + relu; 9 waves = 9 kernel cells
-__global__ __launch_bounds__(576) void conv3_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
-    __shared__ float red[9 * 16 * 64];
-    const Slice s = sl.s[blockIdx.z];
-    const int M = s.count * 25, tile = blockIdx.x, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int ky = wave / 3, kx = wave - ky * 3;
-    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
-    const int iy = oy + ky - 1, ix = ox + kx - 1;
-    const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
-    const float *arun = h2 + ((size_t)(s.s_off + (ok ? b : 0)) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
-    const float *bcol = s.params + OFF_W3 + ((size_t)(wave * 64) + 32 * hl) * 64 + n0 + j;
-    f32x16 acc = {0};
-    mma_run_col<32>(arun, ok, bcol, 64, acc, sl.rb);
-    const float bias = s.params[OFF_B3 + n0 + j];
-    reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(v + bias, 0.f); });
-}
-
 // ---- conv1 on the bf16 matrix cores, exactly.
 // conv1's input is u8 (in practice 0 / 255): every u8 value is exact in bf16 (8 significant bits).  Each fp32
 // weight is split into three bf16 parts w = hi + mid + lo (8 + 8 + 8 mantissa bits, exact), so
@@ -287,24 +249,49 @@ __device__ __forceinline__ uint4 nib_lut_entry(unsigned t) {   // byte t = 2 pix
 // the 25.6 KB/env currentState expansion (its own launch before) disappears.
 constexpr int WSP_W2 = 0, WSP_W3 = 64 * 3 * 64, WSP_WF1 = WSP_W3 + 72 * 3 * 64;     // uint4 offsets inside wsp
 
+// Item space of the re-split: one item = 8 weights -> one 16-byte entry in each of the three planes.
+//   [0, 4096)                W_conv2 forward   wsp[WSP_W2 ]: [k8 = (tap, ci / 8)][plane][co]          (k = tap * 32 + ci)
+//   [4096, 8704)             W_conv3 forward   wsp[WSP_W3 ]: [k8 = (tap, ci / 8)][plane][co]
+//   [8704, 8704 + 200 FC)    W_fc1             wsp[WSP_WF1]: [k8][plane][unit]
+//   then 4608 + 4096 items   the conv weights TRANSPOSED for the data gradients (conv32_bx_kernel):
+//                            wsp[W3T]: [tap * 8 + co / 8][plane][ci (64)], wsp[W2T]: [tap * 8 + co / 8][plane][ci (32)]   (8 consecutive co)
+constexpr int IT_CONV = 64 * 64 + 72 * 64;
+__host__ __device__ __forceinline__ int wsp_w3t(int FC) { return WSP_WF1 + (200 + 4) * 3 * FC; }      // (+ 4: fc1_sp_kernel over-reads a chunk)
+__host__ __device__ __forceinline__ int wsp_w2t(int FC) { return wsp_w3t(FC) + 72 * 3 * 64; }
+__host__ __device__ __forceinline__ int wsp_total(int FC) { return wsp_w2t(FC) + 128 * 3 * 32; }
+__host__ __device__ __forceinline__ int wsplit_items(int FC) { return 2 * IT_CONV + 200 * FC; }
+// item of the conv-only job (forward + transposed conv planes, no fc1): q in [0, 2 IT_CONV)
+__device__ __forceinline__ int conv_item(int q, int FC) { return q < IT_CONV ? q : q + 200 * FC; }
+
 __device__ __forceinline__ void wsplit_item(const float *__restrict__ params, uint4 *__restrict__ wsp, int FC, int id) {
-    const float *W; uint4 *out; int N;
-    if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
-    else if (id < 64 * 64 + 72 * 64) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
-    else { id -= 64 * 64 + 72 * 64; if (id >= 200 * FC) return; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
-    const int k8 = id / N, col = id - k8 * N;
-    // plane 0: fp16 h, plane 1: fp16 l (split2x2), plane 2: the weight rounded to bf16 (bf16 inference mode, FB_DTYPE_BF16)
+    float w[8];
+    uint4 *o; int pstride;
+    const int t0 = IT_CONV + 200 * FC;
+    if (id < t0) {                                                       // k-strided gather: W[k8 * 8 + e][col]
+        const float *W; uint4 *out; int N;
+        if (id < 64 * 64) { W = params + OFF_W2; out = wsp + WSP_W2; N = 64; }
+        else if (id < IT_CONV) { id -= 64 * 64; W = params + OFF_W3; out = wsp + WSP_W3; N = 64; }
+        else { id -= IT_CONV; W = params + OFF_WF1; out = wsp + WSP_WF1; N = FC; }
+        const int k8 = id / N, col = id - k8 * N;
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = W[(size_t)(k8 * 8 + e) * N + col];
+        o = out + (size_t)k8 * 3 * N + col; pstride = N;
+    } else {                                                             // transposed: 8 consecutive co of one (tap, ci)
+        id -= t0;
+        if (id >= IT_CONV) return;
+        const float *src;
+        if (id < 72 * 64) { const int kk = id >> 6, ci = id & 63; src = params + OFF_W3 + ((kk >> 3) * 64 + ci) * 64 + (kk & 7) * 8; o = wsp + wsp_w3t(FC) + kk * 3 * 64 + ci; pstride = 64; }
+        else { id -= 72 * 64; const int kk = id >> 5, ci = id & 31; src = params + OFF_W2 + ((kk >> 3) * 32 + ci) * 64 + (kk & 7) * 8; o = wsp + wsp_w2t(FC) + kk * 3 * 32 + ci; pstride = 32; }
+        const float4 x = reinterpret_cast<const float4 *>(src)[0], y = reinterpret_cast<const float4 *>(src)[1];
+        w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
+    }
+    // plane 0: fp16 h, plane 1: fp16 l (split2x2), plane 2: the weight rounded to bf16 (bf16 mode, FB_DTYPE_BF16)
     uint32_t hi[4], lo[4], bh[4], m_, l_;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const float w0 = W[(size_t)(k8 * 8 + 2 * e) * N + col], w1 = W[(size_t)(k8 * 8 + 2 * e + 1) * N + col];
-        split2x2(w0, w1, hi[e], lo[e]);
-        split3x2(w0, w1, bh[e], m_, l_);
-    }
-    uint4 *o = out + (size_t)k8 * 3 * N + col;
+    for (int e = 0; e < 4; e++) { split2x2(w[2 * e], w[2 * e + 1], hi[e], lo[e]); split3x2(w[2 * e], w[2 * e + 1], bh[e], m_, l_); }
     o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    o[N] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    o[2 * N] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
+    o[pstride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    o[2 * pstride] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
 }
 
 // stand-alone re-split (the acting forward normally does it inside its conv1 launch): only when the versions differ
@@ -325,7 +312,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
 #pragma unroll
         for (int n = 0; n < 2; n++)
             if (job.pver[n] && *job.pver[n] != *job.wverc[n])
-                for (int id = blockIdx.x * 256 + threadIdx.x; id < 64 * 64 + 72 * 64; id += gridDim.x * 256) wsplit_item(job.params[n], job.wsp[n], job.FC, id);
+                for (int q = blockIdx.x * 256 + threadIdx.x; q < 2 * IT_CONV; q += gridDim.x * 256) wsplit_item(job.params[n], job.wsp[n], job.FC, conv_item(q, job.FC));
     }
     if (NIB) {
         lut[threadIdx.x] = nib_lut_entry(threadIdx.x);       // element j = 4*px + f  <->  bit j of the byte
@@ -383,138 +370,6 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
     }
 }
 
-// ---- large-batch variants (the acting path: n = number of envs).  With thousands of output tiles there is no
-// need to split K over waves: every wave owns a whole 32x32 tile, runs the full K loop and writes its
-// result straight from the accumulator -- no LDS, no barrier, and two waves per SIMD hide the loads.
-// Operand fragments for a software pipeline: load_frag() issues the loads of the NEXT k-step while mma_frag()
-// consumes the CURRENT one (one wave per SIMD has nothing else to hide the L2 latency behind).
-template <int KH> struct Frag { float a[KH], b[KH]; };
-
-template <int KH>
-__device__ __forceinline__ void load_frag(Frag<KH> &f, const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
-                                          int bstride) {
-#pragma unroll
-    for (int q = 0; q < KH / 4; q++) {
-        const float4 v = sel4(ok, reinterpret_cast<const float4 *>(arun)[q]);
-        f.a[4 * q] = v.x; f.a[4 * q + 1] = v.y; f.a[4 * q + 2] = v.z; f.a[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int t = 0; t < KH; t++) f.b[t] = bcol[(size_t)t * bstride];
-}
-
-template <int KH>
-__device__ __forceinline__ void mma_frag(const Frag<KH> &f, f32x16 &acc) {
-#pragma unroll
-    for (int t = 0; t < KH; t++) acc = mfma(f.a[t], f.b[t], acc);
-}
-
-__global__ __launch_bounds__(256) void conv2_big_kernel(Slices sl, const float *__restrict__ p1, float *__restrict__ h2) {
-    const Slice s = sl.s[blockIdx.z];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = s.count * 25, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
-    auto issue = [&](int c, Frag<32> &f) {
-        const int ky = c >> 1, kx = 2 * (c & 1) + hl;
-        const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
-        const bool ok = m < M && iy >= 0 && iy < 10 && ix >= 0 && ix < 10;
-        const float *arun = p1 + (((size_t)(s.s_off + (ok ? b : 0)) * 10 + (ok ? iy : 0)) * 10 + (ok ? ix : 0)) * 32;
-        load_frag<32>(f, arun, ok, s.params + OFF_W2 + ((ky * 4 + kx) * 32) * 64 + n0 + j, 64);
-    };
-    f32x16 acc = {0};
-    Frag<32> f0, f1;
-    issue(0, f0);
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        issue(c + 1, f1);
-        mma_frag<32>(f0, acc);
-        if (c + 2 < 8) issue(c + 2, f0);
-        mma_frag<32>(f1, acc);
-    }
-    const float bias = s.params[OFF_B2 + n0 + j];
-    for_rows(tile * 32, M, lane, [&](int r, int mr) { h2[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
-}
-
-__global__ __launch_bounds__(256) void conv3_big_kernel(Slices sl, const float *__restrict__ h2, float *__restrict__ h3) {
-    const Slice s = sl.s[blockIdx.z];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = s.count * 25, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, oy = rem / 5, ox = rem - oy * 5;
-    auto issue = [&](int cell, Frag<32> &f) {
-        const int ky = cell / 3, kx = cell - ky * 3;
-        const int iy = oy + ky - 1, ix = ox + kx - 1;
-        const bool ok = m < M && iy >= 0 && iy < 5 && ix >= 0 && ix < 5;
-        const float *arun = h2 + ((size_t)(s.s_off + (ok ? b : 0)) * 25 + (ok ? iy * 5 + ix : 0)) * 64 + 32 * hl;
-        load_frag<32>(f, arun, ok, s.params + OFF_W3 + ((size_t)(cell * 64) + 32 * hl) * 64 + n0 + j, 64);
-    };
-    f32x16 acc = {0};
-    Frag<32> f0, f1;
-    issue(0, f0);
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        issue(c + 1, f1);
-        mma_frag<32>(f0, acc);
-        issue(c + 2, f0);
-        mma_frag<32>(f1, acc);
-    }
-    mma_frag<32>(f0, acc);
-    const float bias = s.params[OFF_B3 + n0 + j];
-    for_rows(tile * 32, M, lane, [&](int r, int mr) { h3[((size_t)s.s_off * 25 + mr) * 64 + n0 + j] = fmaxf(acc[r] + bias, 0.f); });
-}
-
-// fc1 1600xFC: the K = 1600 reduction is split over FC1_KS = 5 workgroups x 8 waves x 40 k, so every wave
-// issues its 40 operand loads at once and runs 20 MFMAs.  The 5 partial sums stay separate
-// (hfp[ks][sample][FC], no bias / relu yet): the two consumers (head_kernel, loss_head_kernel) add them in
-// a fixed order -- "reduce in the consumer's prologue" instead of one more launch.  (FC1_KS: fb_head.h)
-
-__global__ __launch_bounds__(512) void fc1_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
-                                                  int stot) {
-    __shared__ float red[8 * 16 * 64];
-    const int z = blockIdx.z / FC1_KS, ks = blockIdx.z - z * FC1_KS;
-    const Slice s = sl.s[z];
-    const int M = s.count, tile = blockIdx.x, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int m = tile * 32 + i;
-    const bool ok = m < M;
-    const int k0 = ks * 320 + wave * 40 + hl * 20;
-    const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
-    const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
-    f32x16 acc = {0};
-    mma_run_col<20>(arun, ok, bcol, FC, acc);
-    reduce_rows<8>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = v; });
-}
-
-// large-batch fc1: one wave = one m-tile x one n-tile x one of FC1_BIG_KS = 2 k-slices (800 k = 20 steps of 20 k
-// per lane half; with 1024 samples that is exactly one wave per SIMD), software pipelined, no LDS
-constexpr int FC1_BIG_KS = 2;
-
-__global__ __launch_bounds__(256) void fc1_big_kernel(Slices sl, const float *__restrict__ h3, float *__restrict__ hfp, int FC,
-                                                      int stot) {
-    const int z = blockIdx.z / FC1_BIG_KS, ks = blockIdx.z - z * FC1_BIG_KS;
-    const Slice s = sl.s[z];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = s.count, tile = blockIdx.x * 4 + wave, n0 = blockIdx.y * 32;
-    if (tile * 32 >= M) return;
-    const int m = tile * 32 + i;
-    const bool ok = m < M;
-    const int k0 = ks * 800 + hl * 400;
-    const float *arun = h3 + (size_t)(s.s_off + (ok ? m : 0)) * 1600 + k0;
-    const float *bcol = s.params + OFF_WF1 + (size_t)k0 * FC + n0 + j;
-    f32x16 acc = {0};
-    Frag<20> f0, f1;
-    load_frag<20>(f0, arun, ok, bcol, FC);
-#pragma unroll 2
-    for (int c = 0; c < 20; c += 2) {
-        load_frag<20>(f1, arun + 20 * (c + 1), ok, bcol + (size_t)20 * (c + 1) * FC, FC);
-        mma_frag<20>(f0, acc);
-        if (c + 2 < 20) load_frag<20>(f0, arun + 20 * (c + 2), ok, bcol + (size_t)20 * (c + 2) * FC, FC);
-        mma_frag<20>(f1, acc);
-    }
-    for_rows(tile * 32, M, lane, [&](int r, int mr) { hfp[((size_t)ks * stot + s.s_off + mr) * FC + n0 + j] = acc[r]; });
-}
-
 // ---- split-bf16 inference path (forward only, >= 256 states: the acting path).
 // An fp32 value is the exact sum of three bf16 numbers hi + mid + lo (8 + 8 + 8 significand bits), so an fp32
 // product a*w is the sum of nine bf16 x bf16 products, each exact in the MFMA's fp32 accumulator.  The six
@@ -570,7 +425,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
     // the parameters changed since wsp was split (decided here, on the device: a replayed hipGraph takes the same decision a
     // live call would); the conv2+conv3 launch that follows records the new version
     if (pver && *pver != *wver) {
-        const int items = 64 * 64 + 72 * 64 + 200 * FC;
+        const int items = wsplit_items(FC);
         for (int id = blockIdx.x * (64 * C1_WAVES) + threadIdx.x; id < items; id += gridDim.x * (64 * C1_WAVES)) wsplit_item(s.params, wsp, FC, id);
     }
 #pragma unroll
@@ -881,8 +736,9 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 // (conv2_kernel, conv3_kernel) were two launches of ~6.5 + 7.5 us whose matrix work is under a microsecond: what they wait for is
 // the launch, a cold read of what the previous launch wrote, a 32-deep chain of 64-cycle fp32 MFMAs and an LDS reduction -- twice.
 // Here conv1's pooled output of ONE state (12.8 KB fp32) is split into planes in LDS once, conv2's output never leaves the CU, and
-// the 17 weight chunks of 64 k (8 for conv2's 16 taps x 32 channels, 9 for conv3's taps x 64 channels) stream through a 3-slot LDS
-// ring.  8 waves = 2 channel tiles x 4 k-steps of a chunk; the four k partial sums per tile are added through LDS in a fixed order.
+// the 17 weight chunks of 64 k (8 for conv2's 16 taps x 32 channels, 9 for conv3's taps x 64 channels) go from L2 straight into the
+// registers of the one wave that uses them.  8 waves = 2 channel tiles x 4 k-steps of a chunk; the four k partial sums per tile are
+// added through LDS in a fixed order.
 // fp32 side outputs h2 / h3 feed the backward kernels and fc1.  Operands swapped as in conv23_sp_kernel (D = W^T x A^T): a lane owns
 // 4 consecutive channels of one pixel per register quad.
 struct C23T {
@@ -895,8 +751,7 @@ struct C23T {
 template <int NS>
 __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
-    constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RING = ZOFF + 16, RSZ = 8 * NPL * 64, RED = RING + 3 * RSZ;
-    constexpr int NQ = RSZ / 512;                    // uint4 per thread and chunk
+    constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RED = ZOFF + 16;
     __shared__ uint4 smem[RED + 2048];
     float *red = reinterpret_cast<float *>(smem + RED);
     const Slice s = a.sl.s[blockIdx.y];
@@ -905,14 +760,17 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
     const size_t row = (size_t)s.s_off + blockIdx.x;
     const uint4 *w = a.w[blockIdx.y];
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 && a.wverc[tid]) *a.wverc[tid] = *a.pver[tid];
-    struct BSt { uint4 v0, v1; };
-    auto srcB = [&](int c, int q) {
-        const int e = tid + 512 * q, k8l = e / (64 * NPL), pl = (e >> 6) % NPL;
-        return w + ((size_t)(8 * c + k8l) * 3 + P0 + pl) * 64 + (e & 63);
+    // Every weight fragment is used by exactly ONE wave (tile ct, k-step kq of chunk c): no sharing, so no LDS staging -- the wave reads
+    // its two 512-byte row segments per plane straight from L2, three chunks ahead, and the chunk loop needs no barrier at all
+    // (an LDS ring here cost a write, a read and a workgroup barrier per chunk for nothing).
+    struct WF { uint4 v[NPL]; };
+    auto loadW = [&](int c) {
+        WF r;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) r.v[p] = w[((size_t)(8 * c + 2 * kq + hl) * 3 + P0 + p) * 64 + ct * 32 + j];
+        return r;
     };
-    auto loadB = [&](int c) { BSt r; r.v0 = *srcB(c, 0); r.v1 = NQ == 2 ? *srcB(c, NQ - 1) : r.v0; return r; };
-    auto storeB = [&](int slot, const BSt r) { smem[RING + slot * RSZ + tid] = r.v0; if (NQ == 2) smem[RING + slot * RSZ + 512 + tid] = r.v1; };
-    BSt b0 = loadB(0), b1 = loadB(1);
+    WF w0 = loadW(0), w1 = loadW(1), w2 = loadW(2);
     {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
         float4 t[2];
 #pragma unroll
@@ -931,8 +789,6 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         }
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
     }
-    storeB(0, b0); storeB(1, b1);
-    BSt bn = loadB(2);
     __syncthreads();
     const int oy = j / 5, ox = j - oy * 5;
     const bool rowok = j < 25;
@@ -981,17 +837,18 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
 #pragma unroll
             for (int p = 0; p < NPL; p++) aidx[p] = ok ? C2O + p * C2_P + pix * 8 + ((2 * kq + hl) ^ ((pix >> 1) & 7)) : ZOFF;
         }
-        uint4 W[NPL], A[NPL];
+        uint4 A[NPL];
 #pragma unroll
-        for (int p = 0; p < NPL; p++) { W[p] = smem[RING + (c % 3) * RSZ + ((2 * kq + hl) * NPL + p) * 64 + ct * 32 + j]; A[p] = smem[aidx[p]]; }
+        for (int p = 0; p < NPL; p++) A[p] = smem[aidx[p]];
+        const WF W = w0;
+        w0 = w1; w1 = w2;
+        if (c + 3 < 17) w2 = loadW(c + 3);
         if constexpr (NS == 3) {
-            acl = mfma_h(W[0], A[1], acl);
-            acl = mfma_h(W[1], A[0], acl);
-            acc = mfma_h(W[0], A[0], acc);
-        } else acc = mfma_b(W[0], A[0], acc);
-        if (c + 2 < 17) { storeB((c + 2) % 3, bn); if (c + 3 < 17) bn = loadB(c + 3); }
-        if (c == 7) finish(s.params + OFF_B2, a.h2, true);               // conv2 done: its output becomes conv3's LDS image
-        __syncthreads();
+            acl = mfma_h(W.v[0], A[1], acl);
+            acl = mfma_h(W.v[1], A[0], acl);
+            acc = mfma_h(W.v[0], A[0], acc);
+        } else acc = mfma_b(W.v[0], A[0], acc);
+        if (c == 7) { finish(s.params + OFF_B2, a.h2, true); __syncthreads(); }      // conv2 done: its output becomes conv3's LDS image
     }
     finish(s.params + OFF_B3, a.h3, false);
 }
@@ -1928,6 +1785,135 @@ __device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *
     });
 }
 
+// ---- conv3 and conv2 data gradients of ONE sample in one workgroup, on the transposed two-plane weights (small batches).
+// dh3 (25 x 64) -> dh2 = relu2' * conv3^T(dh3) -> dp1 = relu1' * conv2^T(dh2), everything between the first load and the last store in
+// LDS: the mirror image of conv23_t_kernel.  17 weight chunks of 64 k through the same 3-slot ring:
+//   (weight fragments come straight from L2 into the one wave that uses them)
+//   conv3^T: 9 chunks = taps, k = 64 output channels; 8 waves = 2 input-channel tiles x 4 k-steps;
+//   conv2^T: stride 2 means input pixel (iy, ix) only meets taps with ky = iy + 1, kx = ix + 1 (mod 2): the 100 input pixels fall into
+//            4 parity classes of 25 with 4 live taps each.  8 chunks = (which of the class's two ky, which kx, which half of the 64
+//            output channels), each holding that tap of EVERY class; 8 waves = 4 classes x 2 k-steps.
+// Side outputs dh2 / dp1 (fp32) feed the weight-gradient tiles of the next launch.
+struct BxArgs { const float *dh3, *h2, *p1; float *dh2, *dp1; const uint4 *w3t, *w2t; };
+
+template <int NS> struct BxLds { static constexpr int NPL = NS == 3 ? 2 : 1, U4 = 2 * NPL * 200 + 16 + 2048; };      // uint4 units
+
+template <int NS>
+__device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *smem) {
+    constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
+    constexpr int C2_P = 200, D2O = NPL * C2_P, ZOFF = 2 * NPL * C2_P, RED = ZOFF + 16;
+    float *red = reinterpret_cast<float *>(smem + RED);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = lane & 31;
+    const bool rowok = j < 25;
+    // weight fragments: one wave per fragment, straight from L2, three chunks ahead (see conv23_t_kernel)
+    struct WF { uint4 v[NPL]; };
+    auto loadW = [&](int cc) {
+        WF r;
+        if (cc < 9) {                                                    // conv3^T: rows 8 cc + 2 kq + hl of W3T, columns of tile ct
+            const int ct = wave & 1, kq = wave >> 1;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) r.v[p] = a.w3t[((size_t)(8 * cc + 2 * kq + hl) * 3 + P0 + p) * 64 + ct * 32 + j];
+        } else {                                                         // conv2^T: this class's tap (a2, b2), co half coh, k-step ks
+            const int c2 = cc - 9, a2 = c2 >> 2, b2 = (c2 >> 1) & 1, coh = c2 & 1, cls = wave & 3, ks = wave >> 2;
+            const int tap = ((((cls >> 1) + 1) & 1) + 2 * a2) * 4 + (((cls & 1) + 1) & 1) + 2 * b2;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) r.v[p] = a.w2t[((size_t)(tap * 8 + coh * 4 + 2 * ks + hl) * 3 + P0 + p) * 32 + j];
+        }
+        return r;
+    };
+    WF w0 = loadW(0), w1 = loadW(1), w2 = loadW(2);
+    // roles of the two finishing passes, and the masks they need (requested now)
+    const int ctA = wave & 1, qA = wave >> 1, chA = ctA * 32 + 8 * qA + 4 * hl;                 // conv3^T: channels chA .. + 3 of pixel j
+    const float4 m2 = *reinterpret_cast<const float4 *>(a.h2 + ((size_t)b * 25 + (rowok ? j : 0)) * 64 + chA);
+    const int clsB = wave & 3, halfB = wave >> 2, qy = j / 5, qx = j - qy * 5;
+    const int pixB = ((clsB >> 1) + 2 * qy) * 10 + (clsB & 1) + 2 * qx, ciB = 16 * halfB + 4 * hl;   // conv2^T: channels ciB.. and ciB + 8..
+    const float *p1p = a.p1 + ((size_t)b * 100 + (rowok ? pixB : 0)) * 32 + ciB;
+    const float4 m1a = reinterpret_cast<const float4 *>(p1p)[0], m1b = reinterpret_cast<const float4 *>(p1p)[2];
+    {   // dh3 of the sample -> planes [25 pixels][8 pieces of 8 channels], piece q on q ^ ((pix >> 1) & 7)
+        const int i = tid < 400 ? tid : 0, pix = i >> 4, q16 = i & 15;
+        const float4 t = reinterpret_cast<const float4 *>(a.dh3 + (size_t)b * 1600)[i];
+        uint32_t h0, l0, h1, l1, m_;
+        if constexpr (NS == 3) { split2x2(t.x, t.y, h0, l0); split2x2(t.z, t.w, h1, l1); }
+        else { split3x2(t.x, t.y, h0, m_, l0); split3x2(t.z, t.w, h1, m_, l1); }
+        if (tid < 400) {
+            uint2 *d = reinterpret_cast<uint2 *>(smem + pix * 8 + ((q16 >> 1) ^ ((pix >> 1) & 7))) + (q16 & 1);
+            d[0] = make_uint2(h0, h1);
+            if (NS == 3) d[2 * C2_P] = make_uint2(l0, l1);
+        }
+        if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    f32x16 acc = {0}, acl = {0};
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(slot * 16 + r) * 64 + lane] = NS == 3 ? fmaf(acl[r], F16_LO_UNSCALE, acc[r]) : acc[r];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[r] = 0.f; acl[r] = 0.f; }
+        __syncthreads();
+    };
+    const int iyA = j / 5, ixA = j - iyA * 5;
+#pragma unroll
+    for (int cc = 0; cc < 17; cc++) {
+        int aidx[NPL];
+        if (cc < 9) {                                                    // conv3^T, tap cc: output pixel = input pixel + 1 - tap
+            const int kq = wave >> 1, ky = cc / 3, oy = iyA + 1 - ky, ox = ixA + 1 - (cc - 3 * ky), pix = oy * 5 + ox;
+            const bool ok = rowok && oy >= 0 && oy < 5 && ox >= 0 && ox < 5;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) aidx[p] = ok ? p * C2_P + pix * 8 + ((2 * kq + hl) ^ ((pix >> 1) & 7)) : ZOFF;
+        } else {                                                         // conv2^T, this class's tap (a2, b2), co half coh, k-step ks
+            const int c2 = cc - 9, a2 = c2 >> 2, b2 = (c2 >> 1) & 1, coh = c2 & 1, ks = wave >> 2;
+            const int py = clsB >> 1, px = clsB & 1, ky = ((py + 1) & 1) + 2 * a2, kx = ((px + 1) & 1) + 2 * b2;
+            const int ty = py + 2 * qy + 1 - ky, tx = px + 2 * qx + 1 - kx, oy = ty >> 1, ox = tx >> 1, pix = oy * 5 + ox;
+            const bool ok = rowok && ty >= 0 && tx >= 0 && oy < 5 && ox < 5;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) aidx[p] = ok ? D2O + p * C2_P + pix * 8 + ((coh * 4 + 2 * ks + hl) ^ ((pix >> 1) & 7)) : ZOFF;
+        }
+        uint4 A[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; p++) A[p] = smem[aidx[p]];
+        const WF W = w0;
+        w0 = w1; w1 = w2;
+        if (cc + 3 < 17) w2 = loadW(cc + 3);
+        if constexpr (NS == 3) {
+            acl = mfma_h(W.v[0], A[1], acl);
+            acl = mfma_h(W.v[1], A[0], acl);
+            acc = mfma_h(W.v[0], A[0], acc);
+        } else acc = mfma_b(W.v[0], A[0], acc);
+        if (cc == 8) {
+            // dh2: the four k partial sums per channel tile in k order, masked by relu2 (h2 > 0); fp32 out + planes for conv2^T
+            park((wave >> 1) * 2 + (wave & 1));
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[e] = red[((0 * 2 + ctA) * 16 + 4 * qA + e) * 64 + lane];
+#pragma unroll
+                for (int k = 1; k < 4; k++) v[e] += red[((k * 2 + ctA) * 16 + 4 * qA + e) * 64 + lane];
+            }
+            v[0] = m2.x > 0.f ? v[0] : 0.f; v[1] = m2.y > 0.f ? v[1] : 0.f; v[2] = m2.z > 0.f ? v[2] : 0.f; v[3] = m2.w > 0.f ? v[3] : 0.f;
+            if (rowok) {
+                *reinterpret_cast<float4 *>(a.dh2 + ((size_t)b * 25 + j) * 64 + chA) = make_float4(v[0], v[1], v[2], v[3]);
+                uint32_t h0, l0, h1, l1, m_;
+                if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
+                else { split3x2(v[0], v[1], h0, m_, l0); split3x2(v[2], v[3], h1, m_, l1); }
+                uint2 *d = reinterpret_cast<uint2 *>(smem + D2O + j * 8 + ((ctA * 4 + qA) ^ ((j >> 1) & 7))) + hl;
+                d[0] = make_uint2(h0, h1);
+                if (NS == 3) d[2 * C2_P] = make_uint2(l0, l1);
+            }
+            __syncthreads();                                             // dh2's planes are complete before conv2^T reads them
+        }
+    }
+    // dp1: the two k-step partial sums per class, masked by relu1 through the pool (p1 > 0)
+    park((wave >> 2) * 4 + (wave & 3));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = red[((0 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane] + red[((1 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane];
+    if (rowok) {
+        float *o = a.dp1 + ((size_t)b * 100 + pixB) * 32 + ciB;
+        reinterpret_cast<float4 *>(o)[0] = make_float4(m1a.x > 0.f ? v[0] : 0.f, m1a.y > 0.f ? v[1] : 0.f, m1a.z > 0.f ? v[2] : 0.f, m1a.w > 0.f ? v[3] : 0.f);
+        reinterpret_cast<float4 *>(o)[2] = make_float4(m1b.x > 0.f ? v[4] : 0.f, m1b.y > 0.f ? v[5] : 0.f, m1b.z > 0.f ? v[6] : 0.f, m1b.w > 0.f ? v[7] : 0.f);
+    }
+}
+
 // ---- merged backward launches: the weight-gradient tiles and the data-gradient tiles of one layer are
 // independent, so they share one launch (the first n_dx workgroups run the dX body, the rest the dW body):
 // three kernel boundaries fewer per step and the two latency chains overlap.
@@ -2014,14 +2000,15 @@ constexpr int DW1_IMG_W = 104, DW1_IMG_H = 84, DW1_IMG = DW1_IMG_H * DW1_IMG_W *
 constexpr int DW1_STEPS = 30;
 
 // NSP workgroups per sample (each takes 30 / NSP consecutive steps and writes its own slab: small batches want more than B workgroups)
+template <int NSP> struct Dw1Lds { static constexpr int U4 = DW1_IMG / 16 + (DW1_STEPS / NSP) * 2 * 64 + 64; };      // uint4 units
+
 template <int NSP>
-__global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restrict__ states, const float *__restrict__ dp1,
-                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, int B) {
+__device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restrict__ states, const float *__restrict__ dp1,
+                                               const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, uint4 *pool) {
     constexpr int SW = DW1_STEPS / NSP, PU = (SW + 7) / 8;       // steps of this workgroup; fragment-building rounds per wave
-    __shared__ uint4 img4[DW1_IMG / 16];
-    __shared__ uint4 bfr[SW * 2 * 64];
-    __shared__ float bsum[8][32];
-    const int b = blockIdx.x / NSP, part = blockIdx.x - b * NSP, s0 = part * SW;
+    uint4 *img4 = pool, *bfr = pool + DW1_IMG / 16;
+    float (*bsum)[32] = reinterpret_cast<float (*)[32]>(bfr + SW * 2 * 64);
+    const int b = blk / NSP, part = blk - b * NSP, s0 = part * SW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, c = lane & 31;
     uint8_t *img = reinterpret_cast<uint8_t *>(img4);
     // ---- this wave's share of the dY fragments: local steps wave, wave + 8, .. ; lane (c, hl) holds pixels (group 2 st + hl, ox0 .. ox0 + 7) of
@@ -2040,15 +2027,17 @@ __global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restric
         }
     }
     // ---- the padded image: zero everything, then the 80 rows of 320 bytes
-    uint4 px4[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int i = tid + 512 * u; px4[u] = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600)[i < 1600 ? i : 0]; }
+    // (named registers, not an array: hipcc parked a 4-entry uint4 array in scratch memory here)
+    const uint4 *sp = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600);
+    const uint4 pxa = sp[tid], pxb = sp[tid + 512], pxc = sp[tid + 1024], pxd = sp[tid + 1536 < 1600 ? tid + 1536 : 0];
     for (int i = tid; i < DW1_IMG / 16; i += 512) img4[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int i = tid + 512 * u, row = i / 20, col4 = i - row * 20;             // 20 uint4 (4 pixels x 4 frames each) per image row
-        if (i < 1600) *reinterpret_cast<uint4 *>(img + ((row + 2) * DW1_IMG_W + 4 + 4 * col4) * 4) = px4[u];
+    {
+        auto put = [&](int i, const uint4 v) {                                       // 20 uint4 (4 pixels x 4 frames each) per image row
+            const int row = i / 20, col4 = i - row * 20;
+            if (i < 1600) *reinterpret_cast<uint4 *>(img + ((row + 2) * DW1_IMG_W + 4 + 4 * col4) * 4) = v;
+        };
+        put(tid, pxa); put(tid + 512, pxb); put(tid + 1024, pxc); put(tid + 1536, pxd);
     }
     float bs = 0.f;
 #pragma unroll
@@ -2103,7 +2092,7 @@ __global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restric
         acl = mfma_h(A, cur.bl, acl);
         cur = nxt;
     }
-    float *o = slabs + (size_t)blockIdx.x * slab_stride;
+    float *o = slabs + (size_t)blk * slab_stride;
 #pragma unroll
     for (int r = 0; r < 16; r++) o[OFF_W1 + (ky * 32 + drow(r, lane)) * 32 + c] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);
     if (wave == 0 && hl == 0) {
@@ -2112,7 +2101,57 @@ __global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restric
         for (int w = 1; w < 8; w++) sum += bsum[w][c];
         o[OFF_B1 + c] = sum;
     }
+}
+
+template <int NSP>
+__global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restrict__ states, const float *__restrict__ dp1,
+                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, int B) {
     (void)B;
+    __shared__ uint4 pool[Dw1Lds<NSP>::U4];
+    conv1_dw2_body<NSP>(blockIdx.x, states, dp1, amax, slabs, slab_stride, pool);
+}
+
+// ---- the backward tail of a small batch in two launches (after fc1_bwd2_kernel):
+//   conv_bx_kernel    B workgroups run the per-sample data-gradient chain (conv32_bx_body); beside them the conv3 weight-gradient tiles
+//                     (they need dh3 and h2 only), W_fc1's Adam span and, in fb_train_steps, the next step's random.sample
+//   conv_dw21_kernel  the conv2 weight-gradient tiles (dh2 is complete now) and conv1's (dp1), side by side
+template <int NS>
+__global__ __launch_bounds__(512) void conv_bx_kernel(BxArgs bx, int B, int nz, float *__restrict__ slabs, size_t slab_stride, int n_adam,
+                                                      AdamSpan span, FbSampleRider rider, int rb) {
+    // one LDS pool for whichever role the workgroup has (separate static arrays would add up: with 134 KB per workgroup the ~400 Adam
+    // workgroups of this launch went one per CU)
+    __shared__ uint4 pool[BxLds<NS>::U4];
+    static_assert(BxLds<NS>::U4 * 16 >= FB_SAMPLE_LDS_WORDS * 4 && BxLds<NS>::U4 >= 2048, "the riders borrow the pool");
+    const int rid = rider.k ? 1 : 0, bid = (int)blockIdx.x - rid;
+    if (bid < 0) {
+        uint32_t *sw = reinterpret_cast<uint32_t *>(pool);
+        if (threadIdx.x < 64) sample_cpython_body(rider.ctx, rider.k, rider.setsize, rider.out, sw, reinterpret_cast<int *>(sw + 624));
+        return;
+    }
+    if (bid < B) { conv32_bx_body<NS>(bx, bid, pool); return; }
+    const int t = bid - B;
+    if (t < 38 * nz) {
+        float *red = reinterpret_cast<float *>(pool);
+        conv_dw_body<3>(t % 38, t / 38, nz, red, B, bx.h2, nullptr, bx.dh3, nullptr, slabs, slab_stride, rb);
+        return;
+    }
+    adam_span_body(t - 38 * nz, n_adam, span);
+}
+
+template <int NSP>
+__global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const float *__restrict__ p1, const float *__restrict__ dh2,
+                                                        const uint8_t *__restrict__ states, const float *__restrict__ dp1,
+                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride,
+                                                        float *__restrict__ slabs1, size_t stride1, int rb) {
+    const int n2 = 34 * nz;                       // (slabs1 / stride1: where conv1's slabs go -- the common slab set, or the fold buffer)
+    __shared__ uint4 pool[Dw1Lds<NSP>::U4];
+    static_assert(Dw1Lds<NSP>::U4 >= 2048, "the conv2 tiles borrow the pool");
+    if ((int)blockIdx.x < n2) {
+        float *red = reinterpret_cast<float *>(pool);
+        conv_dw_body<2>(blockIdx.x % 34, blockIdx.x / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride, rb);
+        return;
+    }
+    conv1_dw2_body<NSP>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool);
 }
 
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
@@ -2268,7 +2307,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     if (max_batch > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)FOLD * h->zmax * CONV1_PARAMS);
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
-    const size_t wsp_bytes = ((size_t)WSP_WF1 + (size_t)(200 + 4) * 3 * fc_width) * sizeof(uint4);   // + one chunk: fc1_sp_kernel over-reads
+    const size_t wsp_bytes = (size_t)wsp_total(fc_width) * sizeof(uint4);
     alloc((void **)&h->wsp[0], wsp_bytes); alloc((void **)&h->wsp[1], wsp_bytes);
     h->nsplit = 3; h->nsplit_train = 3;
     alloc((void **)&h->zeros, 256);
@@ -2544,14 +2583,34 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         FbSampleRider srider;
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
-        FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam + (srider.k ? 1 : 0)), dim3(576), 0, st, ndx3, z3,
+        if (fk) {
+            // small batches: [data-gradient chain per sample + conv3 dW + W_fc1's Adam] and [conv2 dW + conv1 dW] (see conv_bx_kernel)
+            const int nsp1 = 2 * B <= h->zmax ? 2 : 1;
+            const bool fold1 = B > h->zmax;              // more conv1 slabs than the common set holds: 4 : 1 folding afterwards
+            z1 = fold1 ? (B + FOLD - 1) / FOLD : nsp1 * B;
+            const int n_adam5 = (span1 - span0 + 511) / 512;
+            const BxArgs bx{h->dh3, h->h2, h->p1, h->dh2, h->dp1, h->wsp[0] + wsp_w3t(FC), h->wsp[0] + wsp_w2t(FC)};
+            FB_K(K_CONV3_BWD) {
+                const dim3 g(B + 38 * z3 + n_adam5 + (srider.k ? 1 : 0));
+                if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_bx_kernel<3>, g, dim3(512), 0, st, bx, B, z3, h->slabs, ss, n_adam5, span, srider, rbt);
+                else hipLaunchKernelGGL(conv_bx_kernel<1>, g, dim3(512), 0, st, bx, B, z3, h->slabs, ss, n_adam5, span, srider, rbt);
+            }
+            FB_K(K_CONV2_BWD) {
+                if (nsp1 == 2) hipLaunchKernelGGL(conv_dw21_kernel<2>, dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt);
+                else hipLaunchKernelGGL(conv_dw21_kernel<1>, dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
+                                        fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt);
+                if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
+            }
+        }
+        if (!fk) FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam + (srider.k ? 1 : 0)), dim3(576), 0, st, ndx3, z3,
                                              h->params[0], h->dh3, h->h2, h->dh2, h->slabs, ss, B, n_adam, span, srider, rbt);
         const int ndx2 = ((B * 25 + 31) / 32) * 4;
-        FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
+        if (!fk) FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
                                              h->dp1, h->slabs, ss, B, rbt);
         // conv1's weight gradient: one slab per workgroup of conv1_dw2_kernel -- two workgroups per sample while that stays within zmax
         // slabs (small batches need the parallelism), one per sample beyond; more than zmax samples go through 4 : 1 folding
-        if (B > h->zmax) {
+        if (fk) { /* conv1's weight gradient rode in conv_dw21_kernel */ }
+        else if (B > h->zmax) {
             z1 = (B + FOLD - 1) / FOLD;
             FB_K(K_CONV1_DW) {
                 hipLaunchKernelGGL(conv1_dw2_kernel<1>, dim3(B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs1, (size_t)CONV1_PARAMS, B);
@@ -2727,7 +2786,7 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
     if (rc != FB_OK) return rc;
     p.tick = false;
     {                                            // bring both nets' split planes up to date once, outside the timed launches
-        const int items = 64 * 64 + 72 * 64 + 200 * h->FC;
+        const int items = wsplit_items(h->FC);
         for (int n = 0; n < 2; n++) {
             hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, fb_stream(stream), h->params[n], h->wsp[n], h->FC,
                                (const unsigned *)&h->adam->pver[n], (const unsigned *)&h->adam->wver[n]);
