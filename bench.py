@@ -33,9 +33,12 @@ MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense (t
 # algorithmic flops / bytes per launch (n = samples in the launch)
 FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64 * 512,
             "conv3_kernel": 2 * 25 * 64 * 576, "fc1_kernel": 2 * 1600 * 512, "head_kernel": 2 * 512 * 2}
-BWD_FLOP = {"fc1_bwd_kernel": 2 * 2 * 1600 * 512,                 # dW + dX in one launch
-            "conv3_bwd_kernel": 2 * 2 * 25 * 576 * 64, "conv2_bwd_kernel": 2 * 2 * 25 * 512 * 64,
-            "conv1_dw2_kernel": 2 * 400 * 256 * 32}
+FWD_FLOP["conv23_t_kernel"] = FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"]      # conv2 + conv3 of one state in one launch
+FWD_FLOP["fc1_fk_kernel"] = FWD_FLOP["fc1_kernel"] + FWD_FLOP["head_kernel"]           # fc1 + the head's per-tile shares
+BWD_FLOP = {"fc1_bwd2_kernel": 2 * 2 * 1600 * 512,                # loss + head + fc1 dW + dX in one launch
+            # conv3^T + conv2^T data gradients per sample, the conv3 weight gradient beside them (+ W_fc1's Adam span: HBM)
+            "conv_bx_kernel": 2 * 25 * 576 * 64 + 2 * 25 * 512 * 64 + 2 * 25 * 576 * 64,
+            "conv_dw21_kernel": 2 * 25 * 512 * 64 + 2 * 400 * 256 * 32}      # conv2 dW + conv1 dW
 GATHER_BYTES = 102_417          # per sampled transition
 ADAM_BYTES = 28                 # per parameter
 ENV_BYTES = 6_400 + 64          # per env-step
@@ -227,7 +230,7 @@ def main():
             # split = s > 0: the kernel computes every fp32 product as s fp16 x fp16 MFMA products of two-plane operands
             # (DESIGN.md section 4): conv1 2 (its u8 input is exact in fp16), the acting conv2/conv3/fc1 kernels 3; priced
             # against the dense fp16 MFMA peak (= the bf16 one).
-            split = split or (2 if name.startswith("conv1_pool_kernel") else 0)
+            split = split or (2 if name.startswith("conv1_pool_kernel") else 3 if name.startswith("conv23_t_kernel") else 0)
             peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF)
             ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
             k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
@@ -273,12 +276,12 @@ def main():
                 break
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, 0, BATCH, L.ptr(s), L.ptr(a), L.ptr(r),
                                                                   L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
-            if us < 0.2:                                     # not a launch of this plan (head / loss ride in the fc1 kernels at B = 32)
+            if us < 0.8:                                     # not a launch of this plan (rides in a neighbour at B = 32, see fb_qnet_kernel_name)
                 continue
             if name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
-            elif name == "conv3_bwd_kernel":                  # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
-                add(name + "[+ Adam of W_fc1]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
+            elif name == "conv_bx_kernel":                    # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
+                add(name + "[+ conv3 dW + Adam of W_fc1]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
             elif name in BWD_FLOP:
                 add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
             elif name == "adam_kernel":
