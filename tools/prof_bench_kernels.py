@@ -20,6 +20,8 @@ for t in range(5):
     s, aa, r, s2, tt = replay.gather(idx)
     net.train_step("dqn", s, aa, r, s2, tt, want_aux=False)
 big = torch.randint(0, 40000, (4096,), dtype=torch.int64, device="cuda")
+mid = torch.randint(0, 40000, (256,), dtype=torch.int64, device="cuda")
 for _ in range(3):
     replay.gather(big)
+    replay.gather(mid)
 torch.cuda.synchronize()
