@@ -259,7 +259,7 @@ def main():
         st = L.current_stream
         # acting forward, n = 1024
         scratch.act_nib(nib, 0.0)
-        # (>= 256 states, forward only: the split-bf16 kernels; conv3 rides in conv2's launch)
+        # (>= 256 states, forward only: the two-plane fp16 kernels; conv2 + conv3 in one launch)
         act = [(0, "conv1_sp_kernel<nib>", FWD_FLOP["conv1_pool_kernel"], 2),
                (1, "conv23_sp_kernel", FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"], 3),
                (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 3), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]

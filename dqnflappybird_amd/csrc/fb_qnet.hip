@@ -372,12 +372,11 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
     }
 }
 
-// ---- split-bf16 inference path (forward only, >= 256 states: the acting path).
-// An fp32 value is the exact sum of three bf16 numbers hi + mid + lo (8 + 8 + 8 significand bits), so an fp32
-// product a*w is the sum of nine bf16 x bf16 products, each exact in the MFMA's fp32 accumulator.  The six
-// largest (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) carry everything above 2^-24 relative, the same
-// order as one fp32 rounding, and six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles per 16 k) replace eight
-// v_mfma_f32_32x32x2_f32 (8 x 64 cycles) while leaving the vector ALU to the address arithmetic.
+// ---- two-plane fp16 path (>= 256 states: the acting path, and the forward part of large training batches).
+// An fp32 value is carried as the two fp16 numbers h + l / 4096 described above (split2x2), so an fp32 product a*w is
+// ah*wh + (ah*wl + al*wh) / 4096 (+ al*wl / 2^24, below one fp32 rounding, dropped): three v_mfma_f32_32x32x16_f16
+// (3 x 32 cycles per 16 k), each product exact in the MFMA's fp32 accumulator, replace eight v_mfma_f32_32x32x2_f32
+// (8 x 64 cycles) while leaving the vector ALU to the address arithmetic.  NS = 1: one bf16 plane (the bf16 mode).
 // Activations travel between the layers as three bf16 planes [plane][row][channel]; the weights are
 // re-split (wsplit_kernel) whenever the parameters changed: wsp[k/8][plane][N] x 8 bf16 (16 B).
 // NS = 3: the fp32-equivalent path; NS = 1 uses the hi planes only = plain bf16 inference.
@@ -1009,7 +1008,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
 //   ticks / applies   Adam step counter bookkeeping: the loss kernel advances beta1^t / beta2^t (a "tick") only when the previous
 //                     tick has been consumed by an Adam update (ticks == applies); the Adam kernel marks it consumed
 //   pver / wver       version of the parameters of net 0 / 1 (bumped by whatever writes them: Adam, init, load, target sync) and
-//                     the version the bf16 hi/mid/lo split of W_conv2 / W_conv3 / W_fc1 (wsp) was built from; the acting forward
+//                     the version the fp16 planes of W_conv2 / W_conv3 / W_fc1 (wsp) were split from; the acting forward
 //                     compares the two ON THE DEVICE and re-splits when they differ.  wverc: the same for the W_conv2 / W_conv3 part
 //                     alone, which is all the small-batch conv2+conv3 kernel needs (conv23_t_kernel; a train-only loop re-splits 70 K
 //                     weights per step, not 890 K)
@@ -2219,7 +2218,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
         } else Gv = reinterpret_cast<const float4 *>(g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
         reinterpret_cast<float4 *>(p)[q] = P; reinterpret_cast<float4 *>(m)[q] = Mv; reinterpret_cast<float4 *>(v)[q] = V;
-        if (q * 4 < OFF_B1) {                                    // W_conv1 changed: refresh its bf16 hi/mid/lo split
+        if (q * 4 < OFF_B1) {                                    // W_conv1 changed: refresh its two fp16 planes
             const int idx = (int)q * 4;
             split_w1(P.x, idx, w1s); split_w1(P.y, idx + 1, w1s); split_w1(P.z, idx + 2, w1s); split_w1(P.w, idx + 3, w1s);
         }
@@ -2265,10 +2264,10 @@ struct fb_qnet {
     NetOff off;
     float *params[2], *adam_m, *adam_v, *grad, *slabs;
     float *slabs1;                   // conv1 sub-slabs of large batches (slab_fold_kernel), NULL when max_batch never needs them
-    uint16_t *w1s[2];                // bf16 hi/mid/lo split of W_conv1, [3][8192]
-    uint4 *wsp[2];                   // bf16 hi/mid/lo split of W_conv2, W_conv3, W_fc1 (split-bf16 inference path)
-    uint16_t *zeros;                 // 256 B of zeros (padding source of the split-bf16 kernels)
-    uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [3][S*3200], conv3 out [3][S*1600] bf16
+    uint16_t *w1s[2];                // W_conv1 as two fp16 planes (h, l), [2][8192]
+    uint4 *wsp[2];                   // planes (fp16 h, fp16 l, bf16) of W_conv2, W_conv3, W_fc1 and of the transposed conv weights
+    uint16_t *zeros;                 // 256 B of zeros (padding source of the plane kernels)
+    uint16_t *a1s, *a3s;             // activation planes of that path: conv1 out [2][S*3200], conv3 out [2][S*1600] fp16 (one bf16 plane in bf16 mode)
     int nsplit;                      // 3 = fp32-equivalent (default), 1 = bf16 inference
     int nsplit_train;                // the same for training (fb_qnet_set_train_dtype): 1 = bf16 operands, fp32 accumulation + master weights
     bool adam_ticked;                // host-side hint only (eager calls): the last train step left a tick pending for fb_qnet_apply_adam;

@@ -224,7 +224,7 @@ int fb_qnet_get_adam_state(fb_qnet_t h, float *m, float *v, float *beta_pows_hos
 int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *v, const float *beta_pows_host);
 int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float eps);
 /* Arithmetic of the forward-only path on >= 256 states (fb_qnet_forward / fb_qnet_act / fb_qnet_act_nib):
- *   FB_DTYPE_F32  (default) fp32-equivalent: every fp32 product as six bf16 MFMA products of hi/mid/lo planes
+ *   FB_DTYPE_F32  (default) fp32-equivalent: every fp32 product as three fp16 MFMA products of two planes (x = h + l/4096)
  *   FB_DTYPE_BF16 plain bf16 inference (config 3 of BASELINE.json: "bf16"): activations and weights rounded to
  *                 bf16, fp32 accumulation.  Training and batches < 256 always compute in fp32. */
 #define FB_DTYPE_F32 0
@@ -234,7 +234,7 @@ int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype);
  *   FB_DTYPE_F32  (default) fp32: small batches on the fp32-input matrix instruction, >= 256 states per slice on two-plane fp16
  *   FB_DTYPE_BF16 bf16 training: every GEMM operand (activations, weights, incoming gradients; conv1's u8 input is exact anyway)
  *                 is rounded to bf16, products accumulate in fp32, the master weights and both Adam slots stay fp32.  Gradients
- *                 then agree with fp32 ones to ~1 % per tensor (tests/test_gpu_configs.py states the bound). */
+ *                 then agree with fp32 ones to a few per cent per tensor (tests/test_gpu_configs.py states the bound). */
 int fb_qnet_set_train_dtype(fb_qnet_t h, int dtype);
 /* QValue.eval: states u8[B,80,80,4] -> q f32[B,A] */
 int fb_qnet_forward(fb_qnet_t h, int which, const uint8_t *states, int batch, float *q, void *stream);
