@@ -559,43 +559,56 @@ struct C23Args {
 #ifndef C23_NO_BAR
 #define C23_NO_BAR 0
 #endif
+#ifndef C23_NO_MFMA
+#define C23_NO_MFMA 0
+#endif
+#ifndef C23_EXIT
+#define C23_EXIT 0
+#endif
 template <int NS>
-__global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
+__global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
     // NS = 3: fp32-equivalent arithmetic on two fp16 planes (h, l; three products per step); NS = 1: one bf16 plane
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;             // operand planes in use / first weight plane of wsp
-    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NPL * IN_P, RING = ZOFF + 16, RSZ = 4 * NPL * 64;   // uint4 units
-    __shared__ uint4 smem[RING + 3 * RSZ];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
-    const int s0 = blockIdx.x * 5, ml = wave * 32 + j;
+    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NPL * IN_P, RING = ZOFF + 16, RSZ = 4 * NPL * 64, XCH = RING + 6 * RSZ;   // uint4 units
+    constexpr int NOWN = 17;                 // chunks per wave group
+    __shared__ uint4 smem[XCH + 2048];
+    // EIGHT waves: wave group g = wave >> 2 takes the chunks of parity g (conv2 taps 2 i + g, then conv3 half taps 2 k + g) for the same
+    // four 32-row tiles, so every SIMD holds two waves (w and w + 4) whose LDS reads, ring writes and barrier waits hide behind each
+    // other's MFMAs -- with four waves (one per SIMD) a chunk took MFMA + LDS + barrier + ring time end to end (0.40 us against 0.21 us
+    // of MFMAs; ablation builds -DC23_NO_*).  The two partial sums per output meet through LDS once per convolution; each wave then
+    // finishes the channel tile ct = g.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w4 = wave & 3, grp = wave >> 2, hl = lane >> 5, j = lane & 31;
+    const int s0 = blockIdx.x * 5, ml = w4 * 32 + j;
     if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) { *a.wver = *a.pver; *a.wverc = *a.pver; }
     const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
     const bool rowok = ml < 125;
     int nloc = a.n - s0; if (nloc > 5) nloc = 5;
+    const int ringp = RING + grp * 3 * RSZ;  // this group's three ring slots
     // weight staging registers: named members, no arrays (hipcc otherwise parks them in LDS / scratch)
     struct BSt { uint4 v0, v1; };
-    auto srcB = [&](int cc, int q) {
-        const int e = wave + 4 * q, k8 = e / NPL, pl = e - k8 * NPL;
-        return a.w + (size_t)cc * 768 + (k8 * 3 + P0 + pl) * 64 + lane;
+    auto srcB = [&](int i, int q) {          // own chunk i = chunk 2 i + grp of the weight stream
+        const int e = w4 + 4 * q, k8 = e / NPL, pl = e - k8 * NPL;
+        return a.w + (size_t)(2 * i + grp) * 768 + (k8 * 3 + P0 + pl) * 64 + lane;
     };
-    auto loadB = [&](int cc) {               // by value throughout: a reference into a lambda defeats SROA (staging lands in LDS)
+    auto loadB = [&](int i) {                // by value throughout: a reference into a lambda defeats SROA (staging lands in LDS)
         BSt r;
-        r.v0 = *srcB(cc, 0);
-        if (NPL == 2) r.v1 = *srcB(cc, 1); else r.v1 = r.v0;
+        r.v0 = *srcB(i, 0);
+        if (NPL == 2) r.v1 = *srcB(i, 1); else r.v1 = r.v0;
         return r;
     };
     auto storeB = [&](int slot, const BSt r) {
-        uint4 *d = smem + RING + slot * RSZ + wave * 64 + lane;
+        uint4 *d = smem + ringp + slot * RSZ + w4 * 64 + lane;
         d[0] = r.v0;
         if (NPL == 2) d[256] = r.v1;
     };
     BSt bstA = loadB(0), bstB = loadB(1);
     {   // the five input images, plane by plane; piece q of pixel pix lands on piece (q + (pix >> 2)) & 3
-        uint4 t[NPL][8];
+        uint4 t[NPL][4];
 #pragma unroll
         for (int p = 0; p < NPL; p++)
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int q = threadIdx.x + 256 * r;
+            for (int r = 0; r < 4; r++) {
+                const int q = threadIdx.x + 512 * r;
                 const bool ok = q < nloc * 400;
                 t[p][r] = make_uint4(0u, 0u, 0u, 0u);
                 if (ok) t[p][r] = reinterpret_cast<const uint4 *>(a.p1s + p * a.pl1 + (size_t)s0 * 3200)[q];
@@ -603,24 +616,24 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
 #pragma unroll
         for (int p = 0; p < NPL; p++)
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int q = threadIdx.x + 256 * r, pix = q >> 2;
+            for (int r = 0; r < 4; r++) {
+                const int q = threadIdx.x + 512 * r, pix = q >> 2;
                 if (q < IN_P) smem[p * IN_P + pix * 4 + ((q + (pix >> 2)) & 3)] = t[p][r];
             }
         if (threadIdx.x < 16) smem[ZOFF + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     }
-    // Software pipeline (everything by value -- a reference into a lambda defeats SROA): while the 24 MFMAs of chunk
-    // cc run on fragments already in registers, the fragments of chunk cc + 1 are read from LDS into a second
-    // register set, the staged weights of chunk cc + 2 go into ring slot (cc + 2) % 3 and the global loads of chunk
-    // cc + 4 are issued; one barrier per chunk.
+    // Software pipeline (everything by value -- a reference into a lambda defeats SROA): while the 12 MFMAs of own chunk
+    // i run on fragments already in registers, the fragments of chunk i + 1 are read from LDS into a second
+    // register set, the staged weights of chunk i + 2 go into ring slot (i + 2) % 3 and the global loads of chunk
+    // i + 4 are issued; one barrier per chunk (= per pair of chunks of the weight stream).
     struct Fr { uint4 A[2][NPL]; uint4 W[2][2][NPL]; };
-    auto readW = [&](int cc, Fr f) {
+    auto readW = [&](int i, Fr f) {
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-                for (int p = 0; p < NPL; p++) f.W[s][ct][p] = smem[RING + (cc % 3) * RSZ + ((2 * s + hl) * NPL + p) * 64 + ct * 32 + j];
+                for (int p = 0; p < NPL; p++) f.W[s][ct][p] = smem[ringp + (i % 3) * RSZ + ((2 * s + hl) * NPL + p) * 64 + ct * 32 + j];
         return f;
     };
     auto readA = [&](auto aidx, Fr f) {          // aidx(s, p) -> LDS index of this lane's activation fragment
@@ -663,16 +676,17 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
     __syncthreads();
     storeB(1, bstB); bstB = loadB(3);
     Fr cur = {};
-    cur = readA(a2(0), readW(0, cur));
+    cur = readA(a2(grp), readW(0, cur));
     __syncthreads();
-#define FB_STEP(cc, ST, AIDX_NEXT, HAVE_A)                                                                        \
+    if (C23_EXIT == 1) { if (cur.A[0][0].x == 0x12345u && cur.W[0][0][0].y == 77u) a.a3s[0] = 1; return; }
+#define FB_STEP(i, ST, AIDX_NEXT, HAVE_A)                                                                         \
     {                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acl[0]), "+a"(acl[1]));     /* see compute(): chunk cc's MFMAs stay behind chunk cc - 1's barrier */ \
+        asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acl[0]), "+a"(acl[1]));     /* see compute(): chunk i's MFMAs stay behind chunk i - 1's barrier */ \
         Fr nx = cur;                                                                                                   \
-        if ((cc) + 1 < 34 && !C23_NO_LDSR) { nx = readW((cc) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }        \
+        if ((i) + 1 < NOWN && !C23_NO_LDSR) { nx = readW((i) + 1, nx); if (HAVE_A) nx = readA(AIDX_NEXT, nx); }        \
         compute(cur);                                                                                                  \
-        if ((cc) + 2 < 34 && !C23_NO_W) { storeB(((cc) + 2) % 3, ST); if ((cc) + 4 < 34) ST = loadB((cc) + 4); }       \
+        if ((i) + 2 < NOWN && !C23_NO_W) { storeB(((i) + 2) % 3, ST); if ((i) + 4 < NOWN) ST = loadB((i) + 4); }       \
         /* issue order inside the chunk: one LDS read / ring write / global load behind each MFMA, so that the LDS pipe   \
            and the MFMA pipe run side by side instead of in two phases that the per-chunk barrier keeps in lock step */ \
         /* (12 MFMAs, 12 LDS reads, 2 ring writes, 2 global loads per chunk at NS = 3) */ \
@@ -682,52 +696,60 @@ __global__ __launch_bounds__(256) void conv23_sp_kernel(C23Args a) {
         if (!C23_NO_BAR) __syncthreads();                                                                              \
         cur = nx;                                                                                                      \
     }
-    // relu(acc + bias) of this lane's 32 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half)
+    // The two groups' partial sums of a convolution meet here: every wave parks the channel tile it does NOT finish (ct = 1 - grp) in the
+    // exchange area and, after a barrier, adds its partner's share of the tile it does finish (ct = grp).  Then relu(sum + bias) of this
+    // lane's 16 channels x 1 pixel, split, handed to put(plane, piece 0..7, 8-byte half).
+    float *xch = reinterpret_cast<float *>(smem + XCH);
     auto epilogue = [&](const float *__restrict__ bias, float *__restrict__ side, auto put) {
+        f32x16 mine, other;
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++)
+        for (int r = 0; r < 16; r++) {
+            const float v0 = NS == 3 ? fmaf(acl[0][r], F16_LO_UNSCALE, acc[0][r]) : acc[0][r];
+            const float v1 = NS == 3 ? fmaf(acl[1][r], F16_LO_UNSCALE, acc[1][r]) : acc[1][r];
+            mine[r] = grp ? v1 : v0; other[r] = grp ? v0 : v1;
+            acc[0][r] = 0.f; acc[1][r] = 0.f; acl[0][r] = 0.f; acl[1][r] = 0.f;
+        }
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bias + ct * 32 + 8 * g + 4 * hl);
-                float v[4];
+        for (int r = 0; r < 16; r++) xch[(wave * 16 + r) * 64 + lane] = other[r];
+        __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = NS == 3 ? fmaf(acl[ct][4 * g + e], F16_LO_UNSCALE, acc[ct][4 * g + e]) : acc[ct][4 * g + e];
-                uint32_t h0, l0, h1, l1, m_;
-                if constexpr (NS == 3) {
-                    split2x2(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), h0, l0);
-                    split2x2(fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f), h1, l1);
-                } else {
-                    split3x2(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), h0, m_, l0);
-                    split3x2(fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f), h1, m_, l1);
-                }
-                put(0, ct * 4 + g, make_uint2(h0, h1));
-                if (NS == 3) put(1, ct * 4 + g, make_uint2(l0, l1));
-                if (side && rowok && bl < nloc)
-                    *reinterpret_cast<float4 *>(side + ((size_t)s0 * 25 + ml) * 64 + ct * 32 + 8 * g + 4 * hl) =
-                        make_float4(fmaxf(v[0] + bv.x, 0.f), fmaxf(v[1] + bv.y, 0.f), fmaxf(v[2] + bv.z, 0.f), fmaxf(v[3] + bv.w, 0.f));
+        for (int r = 0; r < 16; r++) mine[r] += xch[((wave ^ 4) * 16 + r) * 64 + lane];
+        const int ct = grp;
 #pragma unroll
-                for (int e = 0; e < 4; e++) { acc[ct][4 * g + e] = 0.f; acl[ct][4 * g + e] = 0.f; }
-            }
+        for (int g = 0; g < 4; g++) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + ct * 32 + 8 * g + 4 * hl);
+            const float o0 = fmaxf(mine[4 * g] + bv.x, 0.f), o1 = fmaxf(mine[4 * g + 1] + bv.y, 0.f), o2 = fmaxf(mine[4 * g + 2] + bv.z, 0.f),
+                        o3 = fmaxf(mine[4 * g + 3] + bv.w, 0.f);
+            uint32_t h0, l0, h1, l1, m_;
+            if constexpr (NS == 3) { split2x2(o0, o1, h0, l0); split2x2(o2, o3, h1, l1); }
+            else { split3x2(o0, o1, h0, m_, l0); split3x2(o2, o3, h1, m_, l1); }
+            put(0, ct * 4 + g, make_uint2(h0, h1));
+            if (NS == 3) put(1, ct * 4 + g, make_uint2(l0, l1));
+            if (side && rowok && bl < nloc)
+                *reinterpret_cast<float4 *>(side + ((size_t)s0 * 25 + ml) * 64 + ct * 32 + 8 * g + 4 * hl) = make_float4(o0, o1, o2, o3);
+        }
     };
-    // ---- conv2
+    // ---- conv2: own chunks 0 .. 7 = taps 2 i + grp
 #pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        FB_STEP(c, bstA, a2(c + 1), true);
-        FB_STEP(c + 1, bstB, a2(c + 2), c + 2 < 16);       // chunk 16's activations do not exist yet
+    for (int i = 0; i < 8; i += 2) {
+        FB_STEP(i, bstA, a2(2 * (i + 1) + grp), true);
+        FB_STEP(i + 1, bstB, a2(2 * (i + 2) + grp), i + 2 < 8);       // conv3's activations do not exist yet
     }
     // its output pixel ml (= bl * 25 + oy * 5 + ox), 64 channels = 8 pieces, piece q on q ^ ((ml >> 1) & 7); aliases the input
-    // images, which every wave has finished reading (barrier at the end of chunk 15)
+    // images, which every wave has finished reading (barrier at the end of the last chunk)
     epilogue(a.b2, a.h2o, [&](int p, int piece, uint2 v) {
         if (rowok) reinterpret_cast<uint2 *>(smem + p * C2_P + ml * 8 + (piece ^ ((ml >> 1) & 7)))[hl] = v;
     });
     __syncthreads();
-    // ---- conv3 (its first weight fragments are already in `cur`)
-    cur = readA(a3(0), cur);
+    if (C23_EXIT == 2) { if (smem[threadIdx.x].x == 0x12345u) a.a3s[0] = 1; return; }
+    // ---- conv3: own chunks 8 .. 16 = half taps 2 k + grp (the first one's weight fragments are already in `cur`)
+    cur = readA(a3(grp), cur);
 #pragma unroll
-    for (int c = 0; c < 18; c += 2) {
-        FB_STEP(16 + c, bstA, a3(c + 1), true);
-        FB_STEP(16 + c + 1, bstB, a3(c + 2), c + 2 < 18);
+    for (int k = 0; k < 8; k += 2) {
+        FB_STEP(8 + k, bstA, a3(2 * (k + 1) + grp), true);
+        FB_STEP(8 + k + 1, bstB, a3(2 * (k + 2) + grp), true);
     }
+    FB_STEP(16, bstA, a3(0), false);
 #undef FB_STEP
     epilogue(a.b3, a.h3o, [&](int p, int piece, uint2 v) {
         if (rowok && bl < nloc)
@@ -1660,14 +1682,12 @@ __device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__
 // operand is 1 in row 0, so row 0 of the tile is the column sum of dY.  Slabs are summed by
 // slab_reduce_kernel in a fixed order.
 template <int LAYER> struct DwGeom;
-template <> struct DwGeom<1> { static constexpr int OH = 20, OW = 20, IH = 80, IW = 80, CI = 4, CO = 32, K = 8, S = 4, P = 2, WOFF = OFF_W1, BOFF = OFF_B1, CELLS = 8, CIT = 1; };
 template <> struct DwGeom<2> { static constexpr int OH = 5, OW = 5, IH = 10, IW = 10, CI = 32, CO = 64, K = 4, S = 2, P = 1, WOFF = OFF_W2, BOFF = OFF_B2, CELLS = 16, CIT = 1; };
 template <> struct DwGeom<3> { static constexpr int OH = 5, OW = 5, IH = 5, IW = 5, CI = 64, CO = 64, K = 3, S = 1, P = 1, WOFF = OFF_W3, BOFF = OFF_B3, CELLS = 9, CIT = 2; };
 
 template <int LAYER>
 __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *red, int B, const float *__restrict__ x,
-                                             const uint8_t *__restrict__ xu8, const float *__restrict__ dy,
-                                             const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, bool rb = false) {
+                                             const float *__restrict__ dy, float *__restrict__ slabs, size_t slab_stride, bool rb = false) {
     using G = DwGeom<LAYER>;
     constexpr int COT = G::CO / 32, WTILES = G::CELLS * G::CIT * COT, OPIX = G::OH * G::OW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
@@ -1676,7 +1696,7 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
     const int cot = bias_tile ? bx - WTILES : tile % COT;
     tile /= COT;
     const int cit = tile % G::CIT, cell = tile / G::CIT;
-    const int ky = LAYER == 1 ? cell : cell / G::K, kx = LAYER == 1 ? 0 : cell - ky * G::K;
+    const int ky = cell / G::K, kx = cell - ky * G::K;
     const int M = B * OPIX, parts = nz * 8;
     int per = (M + parts - 1) / parts; per += per & 1;
     const int mbeg = wave < 8 ? (zslab * 8 + wave) * per : M;        // a 9th wave (merged launches) stays idle
@@ -1686,12 +1706,10 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
         // every load of the chunk is issued unconditionally from a clamped (valid) address -- 48 loads in flight instead
         // of 48 dependent round trips -- pinned (keep), and only then masked by selects
         float a[16], bb[16], dv[16], xv[16];
-        int am[16], xr[16];
         bool mok[16], in[16];
-        int par[16];
         // position c0 of the chunk is wave-uniform: its (sample, oy, ox) come from scalar divisions once; the 32 positions
         // of the chunk then only carry an offset d < 32 through two small mul-shift quotients (exact for the ranges that
-        // can occur: OW = 20 or 5, d + ox0 < 64, oy0 + q < 32) instead of two 32-bit divisions per position and lane
+        // can occur: OW = 5, d + ox0 < 64, oy0 + q < 32) instead of two 32-bit divisions per position and lane
         const int c0s = __builtin_amdgcn_readfirstlane(c0);
         const int b0 = c0s / OPIX, rem0 = c0s - b0 * OPIX, oy0 = rem0 / G::OW, ox0 = rem0 - oy0 * G::OW;
 #pragma unroll
@@ -1700,38 +1718,22 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
             mok[t] = m0 < mend;
             const int d = mok[t] ? 2 * t + hl : 0;                  // rows past the end recompute position c0 (valid) and are masked
             const int m = c0s + d;
-            const int xs = ox0 + d, q = G::OW == 20 ? (xs * 13) >> 8 : (xs * 205) >> 10, ox = xs - q * G::OW;
-            const int ys = oy0 + q, qq = G::OH == 20 ? (ys * 13) >> 8 : (ys * 205) >> 10, oy = ys - qq * G::OH, b = b0 + qq;
+            const int xs = ox0 + d, q = (xs * 205) >> 10, ox = xs - q * G::OW;
+            const int ys = oy0 + q, qq = (ys * 205) >> 10, oy = ys - qq * G::OH, b = b0 + qq;
             const int iy = oy * G::S + ky - G::P;
-            if (LAYER == 1) {
-                // 32-bit unsigned indices (B <= 256: all far below 2^32): no sign extension, no 64-bit multiplies
-                const uint32_t po = ((uint32_t)b * 100u + (uint32_t)((oy >> 1) * 10 + (ox >> 1))) * 32u + (uint32_t)j;
-                am[t] = amax[po];
-                dv[t] = dy[po];
-                par[t] = (oy & 1) * 2 + (ox & 1);
-                const int ix = ox * 4 - 2 + (i >> 2);
-                in[t] = iy >= 0 && iy < 80 && ix >= 0 && ix < 80;
-                xr[t] = xu8[(((uint32_t)b * 80u + (uint32_t)(in[t] ? iy : 0)) * 80u + (uint32_t)(in[t] ? ix : 0)) * 4u + (uint32_t)(i & 3)];
-            } else {
-                am[t] = 0; par[t] = 0; xr[t] = 0;
-                dv[t] = dy[(uint32_t)m * (uint32_t)G::CO + (uint32_t)(cot * 32 + j)];
-                const int ix = ox * G::S + kx - G::P;
-                in[t] = iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
-                xv[t] = x[(((uint32_t)b * G::IH + (uint32_t)(in[t] ? iy : 0)) * G::IW + (uint32_t)(in[t] ? ix : 0)) * G::CI + (uint32_t)(cit * 32 + i)];
-            }
+            dv[t] = dy[(uint32_t)m * (uint32_t)G::CO + (uint32_t)(cot * 32 + j)];
+            const int ix = ox * G::S + kx - G::P;
+            in[t] = iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
+            xv[t] = x[(((uint32_t)b * G::IH + (uint32_t)(in[t] ? iy : 0)) * G::IW + (uint32_t)(in[t] ? ix : 0)) * G::CI + (uint32_t)(cit * 32 + i)];
         }
-        // the pins take the RAW loaded values (a conversion between a load and its pin drags the load down to the pin: the
-        // byte loads of conv1 then went out two at a time, each pair behind a vmcnt(0)), behind a scheduling fence
+        // the pins take the RAW loaded values (a conversion between a load and its pin drags the load down to the pin),
+        // behind a scheduling fence
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 16; t++) { keep(dv[t]); if (LAYER == 1) { keep(xr[t]); keep(am[t]); } else keep(xv[t]); }
-        if (LAYER == 1) {
-#pragma unroll
-            for (int t = 0; t < 16; t++) xv[t] = (float)xr[t];
-        }
+        for (int t = 0; t < 16; t++) { keep(dv[t]); keep(xv[t]); }
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            bb[t] = mok[t] && am[t] == par[t] ? dv[t] : 0.f;                         // max_pool routes to the arg max
+            bb[t] = mok[t] ? dv[t] : 0.f;
             a[t] = bias_tile ? (mok[t] && i == 0 ? 1.f : 0.f) : (mok[t] && in[t] ? xv[t] : 0.f);
         }
 #pragma unroll
@@ -1742,54 +1744,14 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
         if (bias_tile) {
             if (row32 == 0) o[G::BOFF + cot * 32 + j] = v;                           // row 0 = column sums
         } else {
-            const int row = LAYER == 1 ? (ky * 32 + row32) : (cell * G::CI + cit * 32 + row32);
+            const int row = cell * G::CI + cit * 32 + row32;
             o[G::WOFF + (size_t)row * G::CO + cot * 32 + j] = v;
         }
     });
 }
 
-// conv3 data gradient -> dh2 (masked by relu2); 9 waves = 9 cells
-__device__ __forceinline__ void conv3_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh3,
-                                              const float *__restrict__ h2, float *__restrict__ dh2, int B, bool rb = false) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = B * 25, tile = blk >> 1, c0 = (blk & 1) * 32;
-    const int ky = wave / 3, kx = wave - ky * 3;
-    const int m = tile * 32 + i, b = m / 25, rem = m - b * 25, iy = rem / 5, ix = rem - iy * 5;
-    const int oy = iy + 1 - ky, ox = ix + 1 - kx;
-    const bool ok = m < M && oy >= 0 && oy < 5 && ox >= 0 && ox < 5;
-    const float *arun = dh3 + ((size_t)(ok ? b : 0) * 25 + (ok ? oy * 5 + ox : 0)) * 64 + 32 * hl;
-    const float *brun = params + OFF_W3 + ((size_t)(wave * 64) + c0 + j) * 64 + 32 * hl;
-    f32x16 acc = {0};
-    mma_run_run<32>(arun, ok, brun, acc, rb);
-    reduce_rows<9>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) { const size_t o = (size_t)mr * 64 + c0 + j; dh2[o] = h2[o] > 0.f ? v : 0.f; });
-}
-
-// conv2 data gradient -> dp1 (masked by relu1 through the pool: p1 > 0).  Stride 2 means an input pixel
-// (iy, ix) only meets the 4 kernel cells with ky = iy + 1 and kx = ix + 1 (mod 2): tiles are built per parity
-// class (blockIdx.y) from the 25 pixels of that class per sample, and the 4 waves take the 4 live cells --
-// a quarter of the MFMAs a class-blind tiling would issue.
-__device__ __forceinline__ void conv2_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ dh2,
-                                              const float *__restrict__ p1, float *__restrict__ dp1, int B, bool rb = false) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int M = B * 25, tile = blk >> 2, py = (blk >> 1) & 1, px = blk & 1;
-    const int ky = ((py + 1) & 1) + 2 * (wave >> 1), kx = ((px + 1) & 1) + 2 * (wave & 1);
-    const int m = tile * 32 + i, b = m / 25, q = m - b * 25, qy = q / 5, qx = q - qy * 5;
-    const int iy = py + 2 * qy, ix = px + 2 * qx;
-    const int ty = iy + 1 - ky, tx = ix + 1 - kx;                 // even by construction
-    const bool ok = wave < 4 && m < M && ty >= 0 && tx >= 0 && (ty >> 1) < 5 && (tx >> 1) < 5;   // waves 4..7 of a merged launch idle
-    const int cell = (ky * 4 + kx) & 15;
-    const float *arun = dh2 + ((size_t)(ok ? b : 0) * 25 + (ok ? (ty >> 1) * 5 + (tx >> 1) : 0)) * 64 + 32 * hl;
-    const float *brun = params + OFF_W2 + ((size_t)(cell * 32) + j) * 64 + 32 * hl;
-    f32x16 acc = {0};
-    if (wave < 4) mma_run_run<32>(arun, ok, brun, acc, rb);
-    reduce_rows<4>(acc, red, wave, lane, tile * 32, M, [&](float v, int, int mr) {
-        const int br = mr / 25, qr = mr - br * 25, qyr = qr / 5, qxr = qr - qyr * 5;
-        const size_t o = ((size_t)br * 100 + (py + 2 * qyr) * 10 + (px + 2 * qxr)) * 32 + j;
-        dp1[o] = p1[o] > 0.f ? v : 0.f;
-    });
-}
-
-// ---- conv3 and conv2 data gradients of ONE sample in one workgroup, on the transposed two-plane weights (small batches).
+// ---- conv3 and conv2 data gradients of ONE sample in one workgroup, on the transposed two-plane weights (every batch size:
+// B = 256 is one workgroup per CU).
 // dh3 (25 x 64) -> dh2 = relu2' * conv3^T(dh3) -> dp1 = relu1' * conv2^T(dh2), everything between the first load and the last store in
 // LDS: the mirror image of conv23_t_kernel.  17 weight chunks of 64 k through the same 3-slot ring:
 //   (weight fragments come straight from L2 into the one wave that uses them)
@@ -1953,40 +1915,6 @@ __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan
     }
 }
 
-__global__ __launch_bounds__(576) void conv3_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
-                                                        const float *__restrict__ dh3, const float *__restrict__ h2,
-                                                        float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, int B,
-                                                        int n_adam, AdamSpan span, FbSampleRider rider, int rb) {
-    __shared__ float red[9 * 16 * 64];
-    static_assert(sizeof(red) >= FB_SAMPLE_LDS_WORDS * 4, "the sampler borrows the reduction buffer");
-    // fb_train_steps: random.sample for the NEXT train step rides as workgroup 0 (one wave of it): it needs the generator
-    // and the memory's size only, and this launch is the longest of the step
-    const int rid = rider.k ? 1 : 0, bid = (int)blockIdx.x - rid;
-    if (bid < 0) {
-        uint32_t *words = reinterpret_cast<uint32_t *>(red);
-        if (threadIdx.x < 64) sample_cpython_body(rider.ctx, rider.k, rider.setsize, rider.out, words, reinterpret_cast<int *>(words + 624));
-        return;
-    }
-    const int n_conv = (int)gridDim.x - rid - n_adam;
-    if (bid >= n_conv) adam_span_body(bid - n_conv, n_adam, span);
-    else if (bid < n_dx) conv3_dx_body(bid, red, params, dh3, h2, dh2, B, rb);
-    else {
-        const int t = bid - n_dx;
-        conv_dw_body<3>(t % 38, t / 38, nz, red, B, h2, nullptr, dh3, nullptr, slabs, slab_stride, rb);
-    }
-}
-
-__global__ __launch_bounds__(512) void conv2_bwd_kernel(int n_dx, int nz, const float *__restrict__ params,
-                                                        const float *__restrict__ dh2, const float *__restrict__ p1,
-                                                        float *__restrict__ dp1, float *__restrict__ slabs, size_t slab_stride, int B, int rb) {
-    __shared__ float red[8 * 16 * 64];
-    if ((int)blockIdx.x < n_dx) conv2_dx_body(blockIdx.x, red, params, dh2, p1, dp1, B, rb);
-    else {
-        const int t = blockIdx.x - n_dx;
-        conv_dw_body<2>(t % 34, t / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride, rb);
-    }
-}
-
 // ---- conv1's weight gradient on the fp16 matrix cores, one sample per workgroup.
 // dW1[(ky, kx, ci)][co] = sum over output pixels of x[4 oy + ky - 2][4 ox + kx - 2][ci] * dY[oy][ox][co], dY = the pooled gradient routed to
 // each pool's maximum.  x is u8 -- exact in fp16 -- so with dY as two fp16 planes (split2x2) the products are exact and TWO
@@ -2107,15 +2035,7 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
     }
 }
 
-template <int NSP>
-__global__ __launch_bounds__(512) void conv1_dw2_kernel(const uint8_t *__restrict__ states, const float *__restrict__ dp1,
-                                                        const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, int B) {
-    (void)B;
-    __shared__ uint4 pool[Dw1Lds<NSP>::U4];
-    conv1_dw2_body<NSP>(blockIdx.x, states, dp1, amax, slabs, slab_stride, pool);
-}
-
-// ---- the backward tail of a small batch in two launches (after fc1_bwd2_kernel):
+// ---- the conv backward of any batch in two launches (after fc1_bwd2_kernel / fc1_bwd_kernel):
 //   conv_bx_kernel    B workgroups run the per-sample data-gradient chain (conv32_bx_body); beside them the conv3 weight-gradient tiles
 //                     (they need dh3 and h2 only), W_fc1's Adam span and, in fb_train_steps, the next step's random.sample
 //   conv_dw21_kernel  the conv2 weight-gradient tiles (dh2 is complete now) and conv1's (dp1), side by side
@@ -2136,7 +2056,7 @@ __global__ __launch_bounds__(512) void conv_bx_kernel(BxArgs bx, int B, int nz, 
     const int t = bid - B;
     if (t < 38 * nz) {
         float *red = reinterpret_cast<float *>(pool);
-        conv_dw_body<3>(t % 38, t / 38, nz, red, B, bx.h2, nullptr, bx.dh3, nullptr, slabs, slab_stride, rb);
+        conv_dw_body<3>(t % 38, t / 38, nz, red, B, bx.h2, bx.dh3, slabs, slab_stride, rb);
         return;
     }
     adam_span_body(t - 38 * nz, n_adam, span);
@@ -2152,7 +2072,7 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
     static_assert(Dw1Lds<NSP>::U4 >= 2048, "the conv2 tiles borrow the pool");
     if ((int)blockIdx.x < n2) {
         float *red = reinterpret_cast<float *>(pool);
-        conv_dw_body<2>(blockIdx.x % 34, blockIdx.x / 34, nz, red, B, p1, nullptr, dh2, nullptr, slabs, slab_stride, rb);
+        conv_dw_body<2>(blockIdx.x % 34, blockIdx.x / 34, nz, red, B, p1, dh2, slabs, slab_stride, rb);
         return;
     }
     conv1_dw2_body<NSP>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool);
@@ -2456,14 +2376,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     int maxc = 0, total = 0;
     for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
     // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
-    const bool big = maxc >= 256;
+    static const int small_env = getenv("FB_SMALL") ? atoi(getenv("FB_SMALL")) : 0;
+    const bool big = maxc >= 256 && !(small_env && p.train);
     // >= 256 states per slice: the LDS-staged two-plane-fp16 kernels (conv1_sp / conv23_sp / fc1_sp).  Forward-only plans take
     // them with one slice; TRAINING plans run them in passes, one per run of consecutive slices that go through the same net
     // (DQN: s and s' in one pass; Nature / PER: s online, s' target; Double: s, s' online + s' target), with fp32 side outputs
     // (pooled conv1 + pool positions, conv2, conv3) for the backward kernels.  nsp: 3 = fp32-equivalent, 1 = bf16 operands.
     const bool sp = big;
     const int nsp = p.train ? h->nsplit_train : h->nsplit;
-    const int t23 = (maxc * 25 + 31) / 32, t1 = (maxc * 100 + 7) / 8;
+    const int t1 = (maxc * 100 + 7) / 8;
     const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
     const int stot = 3 * h->max_batch;
     if (sp) {
@@ -2492,10 +2413,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC};
             const dim3 gc((rows + 4) / 5), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
-                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(256), 0, st, c23);      // conv3 rides in the same launch
+                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23);      // conv3 rides in the same launch
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
             } else {
-                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(256), 0, st, c23);
+                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23);
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
             }
             z0 = z1;
@@ -2579,16 +2500,14 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.adam = h->adam; L.tick = p.tick; L.rb = rbt;
             hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7), dim3(512), 0, st, L);
         } } else FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, rbt);
-        const int ndx3 = ((B * 25 + 31) / 32) * 2;
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
-        const int n_adam = (span1 - span0 + 575) / 576;
         const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
         FbSampleRider srider;
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
-        if (fk) {
-            // small batches: [data-gradient chain per sample + conv3 dW + W_fc1's Adam] and [conv2 dW + conv1 dW] (see conv_bx_kernel)
+        {
+            // [data-gradient chain per sample + conv3 dW + W_fc1's Adam] and [conv2 dW + conv1 dW] (see conv_bx_kernel)
             const int nsp1 = 2 * B <= h->zmax ? 2 : 1;
             const bool fold1 = B > h->zmax;              // more conv1 slabs than the common set holds: 4 : 1 folding afterwards
             z1 = fold1 ? (B + FOLD - 1) / FOLD : nsp1 * B;
@@ -2605,27 +2524,6 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                                         fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
             }
-        }
-        if (!fk) FB_K(K_CONV3_BWD) hipLaunchKernelGGL(conv3_bwd_kernel, dim3(ndx3 + 38 * z3 + n_adam + (srider.k ? 1 : 0)), dim3(576), 0, st, ndx3, z3,
-                                             h->params[0], h->dh3, h->h2, h->dh2, h->slabs, ss, B, n_adam, span, srider, rbt);
-        const int ndx2 = ((B * 25 + 31) / 32) * 4;
-        if (!fk) FB_K(K_CONV2_BWD) hipLaunchKernelGGL(conv2_bwd_kernel, dim3(ndx2 + 34 * z2), dim3(512), 0, st, ndx2, z2, h->params[0], h->dh2, h->p1,
-                                             h->dp1, h->slabs, ss, B, rbt);
-        // conv1's weight gradient: one slab per workgroup of conv1_dw2_kernel -- two workgroups per sample while that stays within zmax
-        // slabs (small batches need the parallelism), one per sample beyond; more than zmax samples go through 4 : 1 folding
-        if (fk) { /* conv1's weight gradient rode in conv_dw21_kernel */ }
-        else if (B > h->zmax) {
-            z1 = (B + FOLD - 1) / FOLD;
-            FB_K(K_CONV1_DW) {
-                hipLaunchKernelGGL(conv1_dw2_kernel<1>, dim3(B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs1, (size_t)CONV1_PARAMS, B);
-                hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
-            }
-        } else if (2 * B <= h->zmax) {
-            z1 = 2 * B;
-            FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw2_kernel<2>, dim3(2 * B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs, ss, B);
-        } else {
-            z1 = B;
-            FB_K(K_CONV1_DW) hipLaunchKernelGGL(conv1_dw2_kernel<1>, dim3(B), dim3(512), 0, st, p.s, h->dp1, h->amax, h->slabs, ss, B);
         }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
