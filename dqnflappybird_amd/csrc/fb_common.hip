@@ -115,6 +115,16 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
         else rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
     } else if (train && !have_s) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
     if (rc != FB_OK || !train) return rc;
+    // Batches below 256: no gather.  The train step's first launch reads the sampled transitions' 1-bit frames in the ring itself
+    // (conv trunk per state) and leaves a / r / t behind; the split conv planes it needs are current because the acting forward above
+    // has just refreshed them.  (b->s / b->s2 stay untouched then.)
+    static const bool ring_on = !(getenv("FB_VEC_RING") && atoi(getenv("FB_VEC_RING")) == 0);      // tuning / A-B knob
+    if (ring_on && batch < 256 && n_envs >= 256) {
+        FbRingSrc ring;
+        rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
+        if (rc != FB_OK) return rc;
+        return fb_qnet_train_step_ring(net, algo, batch, &ring, gamma, b->loss, b->flat_grad, stream);
+    }
     rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
     if (rc != FB_OK) return rc;
     return fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, nullptr, gamma, b->loss, nullptr, nullptr, b->flat_grad,

@@ -8,6 +8,24 @@ __device__ __forceinline__ size_t fb_frame_off(const FbGatherCtx &P, long long f
     return ((size_t)(f % P.t_f) * P.n_envs + e) * 100;
 }
 
+// Where transition `j` of a sampled minibatch lives: (tt, e) = (time slot, env) of its frame t; its window is frames tt - 3 .. tt + 1 of
+// env e.  j is a deque position (uniform memory, 0 = oldest) or a SumTree leaf index (prioritized memory); an index outside the
+// filled part raises the memory's error flag (when `flag`) and reads transition 0.
+__device__ __forceinline__ void fb_ring_locate(const FbGatherCtx &P, long long steps, long long j, bool flag, long long &tt, int &e) {
+    const long long total = steps * P.n_envs;
+    long long g;
+    if (P.kind == FB_REPLAY_PER) {
+        long long d = j - (P.cap - 1);
+        if (d < 0 || d >= P.cap || d >= total) { if (flag) *P.error = 1; d = 0; }
+        g = d + P.cap * ((total - 1 - d) / P.cap);  // newest transition living in data slot d
+    } else {
+        const long long size = total < P.cap ? total : P.cap;
+        if (j < 0 || j >= size) { if (flag) *P.error = 1; j = 0; }
+        g = total - size + j;                       // deque position j, 0 = oldest
+    }
+    tt = g / P.n_envs; e = (int)(g - tt * P.n_envs);
+}
+
 // One thread expands 4 pixels x 4 stacked frames = 16 contiguous bytes of s (and of s').
 __device__ __forceinline__ uint32_t expand4(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, int q) {
     return (((n0 >> q) & 1u) * 0xFFu) | (((n1 >> q) & 1u) * 0xFF00u) | (((n2 >> q) & 1u) * 0xFF0000u) |
@@ -25,21 +43,7 @@ __device__ __forceinline__ void gather_body(const FbGatherCtx &P, long long step
     const int b = (int)(tid / 1600), chunk = (int)(tid - (long long)b * 1600);
     long long tt; int e;
     if (CURRENT) { tt = steps; e = b; }
-    else {
-        const long long total = steps * P.n_envs;
-        long long g;
-        if (P.kind == FB_REPLAY_PER) {
-            long long d = idx[b] - (P.cap - 1);
-            if (d < 0 || d >= P.cap || d >= total) { if (chunk == 0) *P.error = 1; d = 0; }
-            g = d + P.cap * ((total - 1 - d) / P.cap);  // newest transition living in data slot d
-        } else {
-            const long long size = total < P.cap ? total : P.cap;
-            long long j = idx[b];
-            if (j < 0 || j >= size) { if (chunk == 0) *P.error = 1; j = 0; }
-            g = total - size + j;                       // deque position j, 0 = oldest
-        }
-        tt = g / P.n_envs; e = (int)(g - tt * P.n_envs);
-    }
+    else fb_ring_locate(P, steps, idx[b], chunk == 0, tt, e);
     const int p = chunk * 4, w = p >> 6, sh = p & 63;
     uint32_t n[5];
 #pragma unroll

@@ -40,7 +40,7 @@ constexpr int CONV_PARAMS = OFF_WF1;         // everything in front of W_fc1
 constexpr int MAXTB = 256;
 
 
-struct Slice { const float *params; const uint8_t *states; int s_off, count; const uint16_t *w1s; };
+struct Slice { const float *params; const uint8_t *states; int s_off, count; const uint16_t *w1s; int fshift; };    // fshift: ring-fed plans, 0 = s, 1 = s'
 struct Slices { Slice s[3]; int rb; };    // rb: bf16 training (fb_qnet_set_train_dtype): GEMM operands are rounded to bf16
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -772,13 +772,25 @@ struct C23T {
     const float *p1; float *h2, *h3;
     const uint4 *w[3];                       // per slice: split weights of its net (wsp + WSP_W2)
     const unsigned *pver[2]; unsigned *wverc[2];     // the launch in front re-split W_conv2 / W_conv3 of a stale net: record it
+    // RING = true (the whole conv trunk of a replay minibatch in this launch, fb_vec_step): the states come straight out of the frame
+    // ring as bits, conv1 + pool run here too (p1o / amax: its fp32 side outputs for the backward pass, rows of slice 0)
+    FbRingSrc ring; float *p1o; uint8_t *amax; unsigned long long *ring_fo;
 };
 
-template <int NS>
+// RING = true: conv1 of the state in front of conv2 + conv3, fed from the replay's 1-bit frame ring.  The workgroup locates its
+// transition (index -> time slot, env), turns the four 800-byte frames of its state into the SAME-padded nibble image the acting conv1
+// uses (one byte = 2 pixels x 4 frames, include/fbdqn.h FB_NIB_*) in LDS, and runs conv1_pool_kernel's tile loop on it: 13 tiles of 8
+// pooled pixels over 8 waves, the operand a 256-entry table lookup.  The pooled output goes into conv2's LDS planes directly (and, for
+// the online pass over s, as fp32 + pool positions to global for the backward kernels).  What this replaces: the gather launch with its
+// 51 KB per transition of u8 expansion, and the conv1 launch.
+template <int NS, bool RING>
 __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
     constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RED = ZOFF + 16;
     __shared__ uint4 smem[RED + 2048];
+    __shared__ uint4 lut[RING ? 256 : 1];
+    __shared__ uint32_t nibw[RING ? FB_NIB_STRIDE / 4 : 1];
+    __shared__ unsigned long long fo[4];
     float *red = reinterpret_cast<float *>(smem + RED);
     const Slice s = a.sl.s[blockIdx.y];
     if ((int)blockIdx.x >= s.count) return;
@@ -797,7 +809,7 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         return r;
     };
     WF w0 = loadW(0), w1 = loadW(1), w2 = loadW(2);
-    {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
+    if constexpr (!RING) {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
         float4 t[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) { const int i = tid + 512 * r; t[r] = reinterpret_cast<const float4 *>(a.p1 + row * 3200)[i < 800 ? i : 0]; }
@@ -814,6 +826,93 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
             }
         }
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        // ---- where the state lives: frames tt - 3 + fshift .. of env e (four threads, one frame offset each)
+        if (tid < 4) {
+            long long tt; int e;
+            fb_ring_locate(a.ring.c, a.ring.steps, a.ring.idx[blockIdx.x], tid == 0 && blockIdx.y == 0, tt, e);
+            const unsigned long long o = fb_frame_off(a.ring.c, tt - 3 + s.fshift + tid, e);
+            fo[tid] = o;
+            if (blockIdx.y == 0) {
+                a.ring_fo[blockIdx.x * 4 + tid] = o;                   // conv1's weight-gradient kernel builds its image from the same frames
+                if (tid == 0) {
+                    const size_t mo = (size_t)(tt % a.ring.c.t_f) * a.ring.c.n_envs + e;
+                    a.ring.a[blockIdx.x] = a.ring.c.act[mo]; a.ring.r[blockIdx.x] = a.ring.c.rew[mo]; a.ring.t[blockIdx.x] = a.ring.c.term[mo];
+                }
+            }
+        }
+        if (tid < 256) lut[tid] = nib_lut_entry(tid);
+        if (tid >= 256 && tid - 256 < FB_NIB_STRIDE / 16) reinterpret_cast<uint4 *>(nibw)[tid - 256] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        // ---- nibble image: group gi = 8 pixels of one row = one byte of each frame -> four nibble bytes (pixel pairs), one 4-byte store
+        const uint8_t *fb = reinterpret_cast<const uint8_t *>(a.ring.c.bits);
+        uint32_t fbyte[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int gi = tid + 512 * r, gc = gi < 800 ? gi : 0;
+#pragma unroll
+            for (int f = 0; f < 4; f++) fbyte[r][f] = fb[fo[f] * 8 + gc];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int gi = tid + 512 * r, y = gi / 10, g = gi - y * 10;
+            uint32_t o = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const uint32_t t2 = (fbyte[r][f] >> (2 * q)) & 3u;           // pixels 2q, 2q + 1 of the group in frame f
+                    o |= ((t2 & 1u) | ((t2 & 2u) << 3)) << (8 * q + f);            // bit 4 * px + f of nibble byte q
+                }
+            if (gi < 800) nibw[((y + 2) * FB_NIB_PITCH + 4 + 4 * g) >> 2] = o;
+        }
+        __syncthreads();
+        // ---- conv1 + bias + relu + 2x2 max pool (conv1_pool_kernel's tile loop on the LDS image): tiles wave, wave + 8 of 13
+        const uint8_t *nib = reinterpret_cast<const uint8_t *>(nibw);
+        const uint4 *WB = reinterpret_cast<const uint4 *>(s.w1s) + hl * 32 + j;      // [part][ky][kq][h][co] x 16 B
+        const float bias = s.params[OFF_B1 + j];
+        for (int tile = wave; tile < 13; tile += 8) {
+            const int P = tile * 8 + (j >> 2), pos = j & 3;
+            const int py = P / 10, px = P - py * 10, oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
+            f32x16 acc = {0}, acl = {0};
+#pragma unroll 2
+            for (int ky = 0; ky < 8; ky++) {
+                const int iy = oy * 4 + ky - 2;
+                const bool rowok = P < 100 && iy >= 0 && iy < 80;
+                const uint8_t *rowp = nib + ((rowok ? iy : 0) + 2) * FB_NIB_PITCH + 4;
+#pragma unroll
+                for (int kq2 = 0; kq2 < 2; kq2++) {
+                    const int ix = ox * 4 - 2 + 4 * kq2 + 2 * hl;        // even: the pixel pair is inside or outside together
+                    const bool ok = rowok && ix >= 0 && ix < 80;
+                    const unsigned idx = rowp[(ok ? ix : 0) >> 1];
+                    const uint4 A = lut[ok ? idx : 0u];                  // entry 0 = all zero = the SAME padding
+                    acc = mfma_h(A, WB[((0 * 8 + ky) * 2 + kq2) * 64], acc);
+                    acl = mfma_h(A, WB[((1 * 8 + ky) * 2 + kq2) * 64], acl);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);      // x*wh + (x*wl) / 4096: exact scale, one rounding
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float bv = fmaxf(acc[4 * g] + bias, 0.f);
+                int best = 0;
+#pragma unroll
+                for (int q = 1; q < 4; q++) {
+                    const float v = fmaxf(acc[4 * g + q] + bias, 0.f);
+                    if (v > bv) { bv = v; best = q; }
+                }
+                const int Pp = tile * 8 + 2 * g + hl;
+                if (Pp < 100) {
+                    if (blockIdx.y == 0) { const size_t o = (row * 100 + Pp) * 32 + j; a.p1o[o] = bv; a.amax[o] = (uint8_t)best; }
+                    uint16_t *d = reinterpret_cast<uint16_t *>(smem + Pp * 4 + (((j >> 3) + (Pp >> 2)) & 3)) + (j & 7);
+                    if constexpr (NS == 3) {
+                        const _Float16 hh = (_Float16)bv, ll = (_Float16)((bv - (float)hh) * F16_LO_SCALE);
+                        d[0] = __builtin_bit_cast(uint16_t, hh); d[IN_P * 8] = __builtin_bit_cast(uint16_t, ll);
+                    } else d[0] = (uint16_t)f32_to_bf16_rn(bv);
+                }
+            }
+        }
     }
     __syncthreads();
     const int oy = j / 5, ox = j - oy * 5;
@@ -1934,9 +2033,12 @@ constexpr int DW1_STEPS = 30;
 // NSP workgroups per sample (each takes 30 / NSP consecutive steps and writes its own slab: small batches want more than B workgroups)
 template <int NSP> struct Dw1Lds { static constexpr int U4 = DW1_IMG / 16 + (DW1_STEPS / NSP) * 2 * 64 + 64; };      // uint4 units
 
-template <int NSP>
+// RING: the sample's image comes out of the replay's 1-bit frames (four frame offsets per sample in ring_fo, left by the trunk kernel)
+struct Dw1Ring { const unsigned long long *bits, *fo; };
+template <int NSP, bool RING = false>
 __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restrict__ states, const float *__restrict__ dp1,
-                                               const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, uint4 *pool) {
+                                               const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride, uint4 *pool,
+                                               Dw1Ring ring = Dw1Ring{nullptr, nullptr}) {
     constexpr int SW = DW1_STEPS / NSP, PU = (SW + 7) / 8;       // steps of this workgroup; fragment-building rounds per wave
     uint4 *img4 = pool, *bfr = pool + DW1_IMG / 16;
     float (*bsum)[32] = reinterpret_cast<float (*)[32]>(bfr + SW * 2 * 64);
@@ -1960,8 +2062,21 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
     }
     // ---- the padded image: zero everything, then the 80 rows of 320 bytes
     // (named registers, not an array: hipcc parked a 4-entry uint4 array in scratch memory here)
-    const uint4 *sp = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600);
-    const uint4 pxa = sp[tid], pxb = sp[tid + 512], pxc = sp[tid + 1024], pxd = sp[tid + 1536 < 1600 ? tid + 1536 : 0];
+    uint4 pxa, pxb, pxc, pxd;
+    if constexpr (!RING) {
+        const uint4 *sp = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600);
+        pxa = sp[tid]; pxb = sp[tid + 512]; pxc = sp[tid + 1024]; pxd = sp[tid + 1536 < 1600 ? tid + 1536 : 0];
+    } else {
+        // chunk i = 4 pixels x 4 frames: a nibble of each frame's bit row, expanded to 0 / 255 bytes (what the gather would have written)
+        const unsigned long long f0 = ring.fo[b * 4], f1 = ring.fo[b * 4 + 1], f2 = ring.fo[b * 4 + 2], f3 = ring.fo[b * 4 + 3];
+        auto chunk = [&](int i) {
+            const int pp = (i < 1600 ? i : 0) * 4, w = pp >> 6, sh = pp & 63;
+            const uint32_t n0 = (uint32_t)(ring.bits[f0 + w] >> sh) & 0xFu, n1 = (uint32_t)(ring.bits[f1 + w] >> sh) & 0xFu,
+                           n2 = (uint32_t)(ring.bits[f2 + w] >> sh) & 0xFu, n3 = (uint32_t)(ring.bits[f3 + w] >> sh) & 0xFu;
+            return make_uint4(expand4(n0, n1, n2, n3, 0), expand4(n0, n1, n2, n3, 1), expand4(n0, n1, n2, n3, 2), expand4(n0, n1, n2, n3, 3));
+        };
+        pxa = chunk(tid); pxb = chunk(tid + 512); pxc = chunk(tid + 1024); pxd = chunk(tid + 1536);
+    }
     for (int i = tid; i < DW1_IMG / 16; i += 512) img4[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     {
@@ -2062,11 +2177,11 @@ __global__ __launch_bounds__(512) void conv_bx_kernel(BxArgs bx, int B, int nz, 
     adam_span_body(t - 38 * nz, n_adam, span);
 }
 
-template <int NSP>
+template <int NSP, bool RING>
 __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const float *__restrict__ p1, const float *__restrict__ dh2,
                                                         const uint8_t *__restrict__ states, const float *__restrict__ dp1,
                                                         const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride,
-                                                        float *__restrict__ slabs1, size_t stride1, int rb) {
+                                                        float *__restrict__ slabs1, size_t stride1, int rb, Dw1Ring ring) {
     const int n2 = 34 * nz;                       // (slabs1 / stride1: where conv1's slabs go -- the common slab set, or the fold buffer)
     __shared__ uint4 pool[Dw1Lds<NSP>::U4];
     static_assert(Dw1Lds<NSP>::U4 >= 2048, "the conv2 tiles borrow the pool");
@@ -2075,7 +2190,7 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
         conv_dw_body<2>(blockIdx.x % 34, blockIdx.x / 34, nz, red, B, p1, dh2, slabs, slab_stride, rb);
         return;
     }
-    conv1_dw2_body<NSP>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool);
+    conv1_dw2_body<NSP, RING>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool, ring);
 }
 
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
@@ -2196,6 +2311,7 @@ struct fb_qnet {
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
     float *qpart;                    // small-batch training: per 16-unit tile shares of the head, [FC/16][S][A + 1]
+    unsigned long long *ring_fo;     // ring-fed training: the four frame offsets of every sample's state s, [max_batch][4]
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
     int zmax;
@@ -2240,6 +2356,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->h2, S * 1600 * 4); alloc((void **)&h->h3, S * 1600 * 4);
     alloc((void **)&h->hf, S * fc_width * 4 * FC1_KS); alloc((void **)&h->q, S * MAXA * 4);
     alloc((void **)&h->qpart, (size_t)(fc_width / 16) * S * (MAXA + 1) * 4);
+    alloc((void **)&h->ring_fo, (size_t)max_batch * 4 * sizeof(unsigned long long));
     const size_t Bm = max_batch;
     alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
     alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
@@ -2296,12 +2413,23 @@ extern "C" int fb_qnet_set_train_dtype(fb_qnet_t h, int dtype) {
     return FB_OK;
 }
 
+// The host replaced a net's parameters (init, load, target sync): bring its split planes up to date right away.  The forward kernels
+// would do it on their own (AdamDev::pver / wver), except the ring-fed conv trunk (conv23_t_kernel<., true>), which has no launch in front
+// of it that could; these are rare events, the launch costs nothing that matters.
+static void resplit_now(fb_qnet *h, int which, hipStream_t st) {
+    const int items = wsplit_items(h->FC);
+    hipLaunchKernelGGL(wsplit_kernel, dim3((items + 255) / 256), dim3(256), 0, st, h->params[which], h->wsp[which], h->FC,
+                       (const unsigned *)&h->adam->pver[which], (const unsigned *)&h->adam->wver[which]);
+    hipLaunchKernelGGL(mark_split_kernel, dim3(1), dim3(1), 0, st, h->adam, which);
+}
+
 extern "C" int fb_qnet_init_params(fb_qnet_t h, int which, uint64_t seed, void *stream) {
     FB_REQUIRE(h && (which == 0 || which == 1), "fb_qnet_init_params: bad argument");
     hipLaunchKernelGGL(init_params_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, fb_stream(stream),
                        h->params[which], h->n, h->off, h->FC, h->A, h->arch == FB_ARCH_DUELING, (uint32_t)seed,
                        (uint32_t)(seed >> 32));
     hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which], &h->adam->pver[which]);
+    resplit_now(h, which, fb_stream(stream));
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -2310,6 +2438,7 @@ extern "C" int fb_qnet_load_params(fb_qnet_t h, int which, const float *flat, vo
     FB_REQUIRE(h && flat && (which == 0 || which == 1), "fb_qnet_load_params: bad argument");
     FB_CHECK_HIP(hipMemcpyAsync(h->params[which], flat, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
     hipLaunchKernelGGL(w1_split_kernel, dim3(32), dim3(256), 0, fb_stream(stream), h->params[which], h->w1s[which], &h->adam->pver[which]);
+    resplit_now(h, which, fb_stream(stream));
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -2369,6 +2498,7 @@ struct Plan {
     FbHeadRider *head_rider;                 // acting path: describe the head work instead of launching it (fb_vec_step)
     const FbSampleRider *sample_rider;       // train plan: random.sample for the next step rides in the conv3 backward launch
     const FbGatherRider *gather_rider;       // ... and its minibatch gather in the Adam launch
+    const FbRingSrc *ring;                   // the minibatch lives in the replay's frame ring (no gathered copies): conv trunk in one launch
 };
 
 static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
@@ -2440,14 +2570,19 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             }
         }
     }
-    if (!sp) FB_K(K_CONV1) {
+    if (!sp && p.ring) FB_K(K_CONV2) {               // ring-fed minibatch: conv1 + pool + conv2 + conv3 of every state in ONE launch
+        c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
+        if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        else hipLaunchKernelGGL((conv23_t_kernel<1, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+    }
+    if (!sp && !p.ring) FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
         if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
         else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
     }
-    if (!sp) FB_K(K_CONV2) {                         // (conv3 rides in the same launch)
-        if (nsp == 3) hipLaunchKernelGGL(conv23_t_kernel<3>, dim3(maxc, p.ns), dim3(512), 0, st, c23t);
-        else hipLaunchKernelGGL(conv23_t_kernel<1>, dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+    if (!sp && !p.ring) FB_K(K_CONV2) {              // (conv3 rides in the same launch)
+        if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, false>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        else hipLaunchKernelGGL((conv23_t_kernel<1, false>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
     }
     // small batches: the whole K per workgroup (fc1_fk_kernel), which lets training skip the head and loss launches
     const bool fk = !sp && !big;
@@ -2519,9 +2654,13 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 else hipLaunchKernelGGL(conv_bx_kernel<1>, g, dim3(512), 0, st, bx, B, z3, h->slabs, ss, n_adam5, span, srider, rbt);
             }
             FB_K(K_CONV2_BWD) {
-                if (nsp1 == 2) hipLaunchKernelGGL(conv_dw21_kernel<2>, dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt);
-                else hipLaunchKernelGGL(conv_dw21_kernel<1>, dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
-                                        fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt);
+                const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
+                if (nsp1 == 2 && p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt, dr);
+                else if (nsp1 == 2) hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt, dr);
+                else if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<1, true>), dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
+                                                    fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt, dr);
+                else hipLaunchKernelGGL((conv_dw21_kernel<1, false>), dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
+                                        fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt, dr);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
             }
         }
@@ -2544,7 +2683,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
 
 static Plan forward_plan(fb_qnet *h, int which, const uint8_t *states, int n) {
     Plan p; memset(&p, 0, sizeof(p));
-    p.sl.s[0] = Slice{h->params[which], states, 0, n, h->w1s[which]};
+    p.sl.s[0] = Slice{h->params[which], states, 0, n, h->w1s[which], 0};
     p.ns = 1; p.which = which;
     return p;
 }
@@ -2625,31 +2764,42 @@ extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     FB_CHECK_HIP(hipMemcpyAsync(h->params[1], h->params[0], sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, fb_stream(stream)));
     FB_CHECK_HIP(hipMemcpyAsync(h->w1s[1], h->w1s[0], 3 * 8192 * 2, hipMemcpyDeviceToDevice, fb_stream(stream)));
     hipLaunchKernelGGL(bump_pver_kernel, dim3(1), dim3(1), 0, fb_stream(stream), h->adam, 1);
+    resplit_now(h, 1, fb_stream(stream));
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
 
 static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,
                       const uint8_t *t, const float *isw, double gamma, float *loss, float *abs_err, float *q_target,
-                      float *flat_grad, Plan *out) {
-    FB_REQUIRE(h && s && a && r && s2 && t && loss, "fb_qnet_train_step: NULL argument");
+                      float *flat_grad, Plan *out, const FbRingSrc *ring = nullptr) {
+    FB_REQUIRE(h && a && r && t && loss && (ring || (s && s2)), "fb_qnet_train_step: NULL argument");
     FB_REQUIRE(algo >= 0 && algo <= 3, "fb_qnet_train_step: unknown algo %d", algo);
     FB_REQUIRE(B >= 1 && B <= h->max_batch && B <= MAXTB, "fb_qnet_train_step: batch %d exceeds min(max_batch, %d)", B, MAXTB);
     FB_REQUIRE(algo != FB_ALGO_PER || isw, "fb_qnet_train_step: PER needs isw");
     Plan p; memset(&p, 0, sizeof(p));
     // forward: s through the online net, s' through the net(s) the algorithm asks for
     p.ns = 2;
-    p.sl.s[0] = Slice{h->params[0], s, 0, B, h->w1s[0]};
-    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]};               // BrainDQN.py:205 (same net)
-    else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0]}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B, h->w1s[1]}; p.ns = 3; }
-    else p.sl.s[1] = Slice{h->params[1], s2, B, B, h->w1s[1]};                                   // target net
+    p.sl.s[0] = Slice{h->params[0], s, 0, B, h->w1s[0], 0};
+    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0], 1};               // BrainDQN.py:205 (same net)
+    else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0], 1}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B, h->w1s[1], 1}; p.ns = 3; }
+    else p.sl.s[1] = Slice{h->params[1], s2, B, B, h->w1s[1], 1};                                // target net
     p.sl.rb = h->nsplit_train == 1;
     p.train = true; p.algo = algo; p.B = B; p.s = s; p.a = a; p.r = r; p.t = t; p.isw = isw; p.gamma = gamma;
     p.loss = loss; p.abs_err = abs_err; p.y = q_target;
     p.G = flat_grad ? flat_grad : h->grad;
     p.apply_adam = flat_grad == nullptr; p.tick = true;
+    p.ring = ring;
     *out = p;
     return FB_OK;
+}
+
+int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, double gamma, float *loss, float *flat_grad, void *stream) {
+    FB_REQUIRE(h && ring && ring->idx && ring->a && ring->r && ring->t, "fb_qnet_train_step_ring: NULL argument");
+    FB_REQUIRE(B < 256 && algo != FB_ALGO_PER, "fb_qnet_train_step_ring: batches below 256 of a uniform memory only");
+    Plan p;
+    int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, nullptr, gamma, loss, nullptr, nullptr, flat_grad, &p, ring);
+    if (rc != FB_OK) return rc;
+    return run_plan(h, p, -1, fb_stream(stream));
 }
 
 int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,

@@ -750,6 +750,13 @@ extern "C" int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms
     return FB_OK;
 }
 
+int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a, float *r, uint8_t *t, FbRingSrc *out) {
+    FB_REQUIRE(h && idx && a && r && t && out, "fb_replay_ring_src: NULL argument");
+    FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_ring_src: batch out of range");
+    *out = FbRingSrc{gather_ctx(h->P), h->host_steps, (const long long *)idx, a, r, t};
+    return FB_OK;
+}
+
 extern "C" int fb_replay_gather(fb_replay_t h, int batch, const int64_t *idx, uint8_t *s, uint8_t *s2, uint8_t *a, float *r,
                                 uint8_t *t, void *stream) {
     FB_REQUIRE(h && idx && s && s2 && a && r && t, "fb_replay_gather: NULL argument");
