@@ -278,10 +278,15 @@ def main():
                                                                   L.ptr(s2), L.ptr(t), L.ptr(loss), st()), "profile"), R)
             if us < 0.8:                                     # not a launch of this plan (rides in a neighbour at B = 32, see fb_qnet_kernel_name)
                 continue
-            if name in FWD_FLOP:
+            if name in ("conv1_pool_kernel", "conv23_t_kernel"):
+                # the train-only leg's first two launches (on a gathered minibatch); the full loop runs the ring-fed trunk below instead
+                add(name + "[train 2B=64, gathered minibatch]", us, 0, "mfma", FWD_FLOP[name] * 2 * BATCH)
+            elif name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
             elif name == "conv_bx_kernel":                    # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
                 add(name + "[+ conv3 dW + Adam of W_fc1]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
+            elif name == "conv_dw21_kernel":
+                add(name + "[gathered minibatch]", us, 0, "mfma", BWD_FLOP[name] * BATCH)      # (full loop: the <ring> variant below)
             elif name in BWD_FLOP:
                 add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
             elif name == "adam_kernel":
@@ -290,7 +295,17 @@ def main():
                 add(name, us, 1, "hbm", 0)
         us = ev_time(lambda: L.check(lib.fb_replay_profile_gather(replay.h, BATCH, L.ptr(idx), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r),
                                                                   L.ptr(t), R, st()), "gather"), R)
-        add("gather_kernel<false>[B=32]", us, 1, "hbm", GATHER_BYTES * BATCH)
+        add("gather_kernel<false>[B=32]", us, 0, "hbm", GATHER_BYTES * BATCH)      # (train-only leg; the full loop has no gather launch)
+        # what the full loop launches instead of gather + conv1 + conv2/3: the conv trunk of every sampled state, fed from the 1-bit ring
+        for k, nm, flop in ((1, "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]",
+                             (FWD_FLOP["conv1_pool_kernel"] + FWD_FLOP["conv23_t_kernel"]) * 2 * BATCH),
+                            (8, "conv_dw21_kernel<ring>", BWD_FLOP["conv_dw21_kernel"] * BATCH)):
+            us = ev_time(lambda: L.check(lib.fb_profile_ring_kernel(replay.h, scratch.h, k, R, 0, BATCH, L.ptr(idx), L.ptr(a), L.ptr(r),
+                                                                    L.ptr(t), L.ptr(loss), st()), "profile ring"), R)
+            c1, c23 = FWD_FLOP["conv1_pool_kernel"], FWD_FLOP["conv23_t_kernel"]
+            add(nm, us, 1, "mfma", flop, (2 * c1 + 3 * c23) / (c1 + c23) if k == 1 else 0)
+            if k == 1:
+                kernels[-1]["dtype"] = "f16x2 (conv1) / f16x3 (conv2, conv3), fp32 result"
         mid = torch.randint(0, 100000, (256,), dtype=torch.int64, device="cuda")
         midrep = [torch.empty((256, 80, 80, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         mm = [torch.empty(256, dtype=dt_, device="cuda") for dt_ in (torch.uint8, torch.float32, torch.uint8)]

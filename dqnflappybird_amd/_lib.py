@@ -77,6 +77,8 @@ SIGNATURES = {
     "fb_train_steps": [_vp, _vp, _i, _i, _i] + [_vp] * 7 + [_d, _vp],
     "fb_qnet_sync_target": [_vp, _vp],
     "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
+    "fb_train_from_replay": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp],
+    "fb_profile_ring_kernel": [_vp, _vp, _i, _i, _i, _i] + [_vp] * 6,
     "fb_qnet_kernel_name": [_i],
     "fb_vec_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _i, _d, _vp],
 }

@@ -115,11 +115,11 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
         else rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
     } else if (train && !have_s) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
     if (rc != FB_OK || !train) return rc;
-    // Batches below 256: no gather.  The train step's first launch reads the sampled transitions' 1-bit frames in the ring itself
+    // No gather (256 envs or more).  The train step's first launch reads the sampled transitions' 1-bit frames in the ring itself
     // (conv trunk per state) and leaves a / r / t behind; the split conv planes it needs are current because the acting forward above
     // has just refreshed them.  (b->s / b->s2 stay untouched then.)
     static const bool ring_on = !(getenv("FB_VEC_RING") && atoi(getenv("FB_VEC_RING")) == 0);      // tuning / A-B knob
-    if (ring_on && batch < 256 && n_envs >= 256) {
+    if (ring_on && n_envs >= 256) {
         FbRingSrc ring;
         rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
         if (rc != FB_OK) return rc;
@@ -129,4 +129,26 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     if (rc != FB_OK) return rc;
     return fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, nullptr, gamma, b->loss, nullptr, nullptr, b->flat_grad,
                               stream);
+}
+
+extern "C" int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, uint8_t *a, float *r,
+                                    uint8_t *t, double gamma, float *loss, float *flat_grad, void *stream) {
+    FB_REQUIRE(replay && net && idx && a && r && t && loss, "fb_train_from_replay: NULL argument");
+    FB_REQUIRE(algo == FB_ALGO_DQN || algo == FB_ALGO_NATURE || algo == FB_ALGO_DOUBLE, "fb_train_from_replay: algo must be DQN, NATURE or DOUBLE");
+    FB_REQUIRE(batch >= 1 && batch <= 256, "fb_train_from_replay: batch must be in 1..256");
+    FbRingSrc ring;
+    int rc = fb_replay_ring_src(replay, batch, idx, a, r, t, &ring);
+    if (rc != FB_OK) return rc;
+    rc = fb_qnet_refresh_planes(net, stream);       // (fb_vec_step needs no such launch: its acting forward has just done it)
+    if (rc != FB_OK) return rc;
+    return fb_qnet_train_step_ring(net, algo, batch, &ring, gamma, loss, flat_grad, stream);
+}
+
+extern "C" int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int reps, int algo, int batch, const int64_t *idx,
+                                      uint8_t *a, float *r, uint8_t *t, float *loss, void *stream) {
+    FB_REQUIRE(replay && net && idx && a && r && t && loss && reps >= 1, "fb_profile_ring_kernel: bad argument");
+    FbRingSrc ring;
+    int rc = fb_replay_ring_src(replay, batch, idx, a, r, t, &ring);
+    if (rc != FB_OK) return rc;
+    return fb_qnet_profile_ring(net, kernel, reps, algo, batch, &ring, loss, stream);
 }

@@ -775,6 +775,7 @@ struct C23T {
     // RING = true (the whole conv trunk of a replay minibatch in this launch, fb_vec_step): the states come straight out of the frame
     // ring as bits, conv1 + pool run here too (p1o / amax: its fp32 side outputs for the backward pass, rows of slice 0)
     FbRingSrc ring; float *p1o; uint8_t *amax; unsigned long long *ring_fo;
+    uint16_t *a3s; size_t pl3;               // conv3's output as planes too ([plane][row * 25 + pixel][64]) when fc1_sp_kernel follows, or NULL
 };
 
 // RING = true: conv1 of the state in front of conv2 + conv3, fed from the replay's 1-bit frame ring.  The workgroup locates its
@@ -936,13 +937,19 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         const float4 bv = *reinterpret_cast<const float4 *>(bias + ch);
         v[0] = fmaxf(v[0] + bv.x, 0.f); v[1] = fmaxf(v[1] + bv.y, 0.f); v[2] = fmaxf(v[2] + bv.z, 0.f); v[3] = fmaxf(v[3] + bv.w, 0.f);
         if (rowok) *reinterpret_cast<float4 *>(out + (row * 25 + j) * 64 + ch) = make_float4(v[0], v[1], v[2], v[3]);
-        if (planes && rowok) {
+        if ((planes || a.a3s) && rowok) {
             uint32_t h0, l0, h1, l1, m_;
             if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
             else { split3x2(v[0], v[1], h0, m_, l0); split3x2(v[2], v[3], h1, m_, l1); }
-            uint2 *d = reinterpret_cast<uint2 *>(smem + C2O + j * 8 + ((ctp * 4 + q) ^ ((j >> 1) & 7))) + hl;
-            d[0] = make_uint2(h0, h1);
-            if (NS == 3) d[2 * C2_P] = make_uint2(l0, l1);
+            if (planes) {
+                uint2 *d = reinterpret_cast<uint2 *>(smem + C2O + j * 8 + ((ctp * 4 + q) ^ ((j >> 1) & 7))) + hl;
+                d[0] = make_uint2(h0, h1);
+                if (NS == 3) d[2 * C2_P] = make_uint2(l0, l1);
+            } else {
+                uint16_t *d = a.a3s + (row * 25 + j) * 64 + ch;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                if (NS == 3) *reinterpret_cast<uint2 *>(d + a.pl3) = make_uint2(l0, l1);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[r] = 0.f; acl[r] = 0.f; }
@@ -2517,6 +2524,31 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     const int t1 = (maxc * 100 + 7) / 8;
     const size_t S = (size_t)3 * h->max_batch, pl1 = S * 3200, pl2 = S * 1600;
     const int stot = 3 * h->max_batch;
+    // small batches: conv2 + conv3 in one launch on the split planes (conv23_t_kernel); the conv1 launch in front re-splits the conv
+    // weights of every net of the plan whose parameters moved (decided on the device), the conv2+conv3 launch records it
+    SplitJob job;
+    C23T c23t;
+    memset(&job, 0, sizeof(job)); memset(&c23t, 0, sizeof(c23t));
+    const bool trunk = p.ring != nullptr;        // ring-fed minibatch (any batch size): the whole conv trunk per state in one launch
+    if (!sp || trunk) {
+        job.FC = h->FC;
+        c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3;
+        for (int z = 0; z < p.ns; z++) {
+            const int which = p.sl.s[z].params == h->params[1] ? 1 : 0;
+            c23t.w[z] = h->wsp[which] + WSP_W2;
+            if (only < 0) {
+                job.params[which] = h->params[which]; job.wsp[which] = h->wsp[which];
+                job.pver[which] = &h->adam->pver[which]; job.wverc[which] = &h->adam->wverc[which];
+                c23t.pver[which] = &h->adam->pver[which]; c23t.wverc[which] = &h->adam->wverc[which];
+            }
+        }
+    }
+    if (trunk) FB_K(K_CONV2) {                       // conv1 + pool + conv2 + conv3 of every state in ONE launch
+        if (sp) { c23t.a3s = h->a3s; c23t.pl3 = pl2; }      // >= 256 states per slice: fc1_sp_kernel follows and reads conv3's output as planes
+        c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
+        if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        else hipLaunchKernelGGL((conv23_t_kernel<1, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+    }
     if (sp) {
         for (int z0 = 0; z0 < p.ns;) {
             int z1 = z0 + 1;
@@ -2534,7 +2566,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             if (z1 - z0 > 1) { side.per = s0.count; side.st1 = p.sl.s[z0 + 1].states; side.st2 = z1 - z0 > 2 ? p.sl.s[z0 + 2].states : p.sl.s[z0 + 1].states; }
             if (p.train) { side.p1 = h->p1; side.amax = h->amax; }
             const int t1p = (rows * 100 + 7) / 8, gsp = min(256, (t1p + C1_WAVES - 1) / C1_WAVES);      // one 12-wave workgroup per CU, the waves stride over the tiles
-            FB_K(K_CONV1) {
+            if (!trunk) FB_K(K_CONV1) {
                 if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
                 else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
             }
@@ -2543,44 +2575,21 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC};
             const dim3 gc((rows + 4) / 5), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
-                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23);      // conv3 rides in the same launch
+                if (!trunk) FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23);      // conv3 rides in the same launch
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
             } else {
-                FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23);
+                if (!trunk) FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23);
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
             }
             z0 = z1;
         }
     }
-    // small batches: conv2 + conv3 in one launch on the split planes (conv23_t_kernel); the conv1 launch in front re-splits the conv
-    // weights of every net of the plan whose parameters moved (decided on the device), the conv2+conv3 launch records it
-    SplitJob job;
-    C23T c23t;
-    memset(&job, 0, sizeof(job)); memset(&c23t, 0, sizeof(c23t));
-    if (!sp) {
-        job.FC = h->FC;
-        c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3;
-        for (int z = 0; z < p.ns; z++) {
-            const int which = p.sl.s[z].params == h->params[1] ? 1 : 0;
-            c23t.w[z] = h->wsp[which] + WSP_W2;
-            if (only < 0) {
-                job.params[which] = h->params[which]; job.wsp[which] = h->wsp[which];
-                job.pver[which] = &h->adam->pver[which]; job.wverc[which] = &h->adam->wverc[which];
-                c23t.pver[which] = &h->adam->pver[which]; c23t.wverc[which] = &h->adam->wverc[which];
-            }
-        }
-    }
-    if (!sp && p.ring) FB_K(K_CONV2) {               // ring-fed minibatch: conv1 + pool + conv2 + conv3 of every state in ONE launch
-        c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
-        if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
-        else hipLaunchKernelGGL((conv23_t_kernel<1, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
-    }
-    if (!sp && !p.ring) FB_K(K_CONV1) {
+    if (!sp && !trunk) FB_K(K_CONV1) {
         const dim3 g1((t1 + 3) / 4, 1, p.ns);
         if (p.nib) hipLaunchKernelGGL(conv1_pool_kernel<true>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
         else hipLaunchKernelGGL(conv1_pool_kernel<false>, g1, dim3(256), 0, st, p.sl, h->p1, h->amax, job);
     }
-    if (!sp && !p.ring) FB_K(K_CONV2) {              // (conv3 rides in the same launch)
+    if (!sp && !trunk) FB_K(K_CONV2) {               // (conv3 rides in the same launch)
         if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, false>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
         else hipLaunchKernelGGL((conv23_t_kernel<1, false>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
     }
@@ -2795,11 +2804,30 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
 
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, double gamma, float *loss, float *flat_grad, void *stream) {
     FB_REQUIRE(h && ring && ring->idx && ring->a && ring->r && ring->t, "fb_qnet_train_step_ring: NULL argument");
-    FB_REQUIRE(B < 256 && algo != FB_ALGO_PER, "fb_qnet_train_step_ring: batches below 256 of a uniform memory only");
+    FB_REQUIRE(algo != FB_ALGO_PER, "fb_qnet_train_step_ring: uniform memories only");
     Plan p;
     int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, nullptr, gamma, loss, nullptr, nullptr, flat_grad, &p, ring);
     if (rc != FB_OK) return rc;
     return run_plan(h, p, -1, fb_stream(stream));
+}
+
+int fb_qnet_refresh_planes(fb_qnet_t h, void *stream) {
+    FB_REQUIRE(h, "fb_qnet_refresh_planes: NULL handle");
+    for (int n = 0; n < 2; n++) resplit_now(h, n, fb_stream(stream));       // (wsplit_kernel returns at once when the versions agree)
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+int fb_qnet_profile_ring(fb_qnet_t h, int kernel, int reps, int algo, int B, const FbRingSrc *ring, float *loss, void *stream) {
+    FB_REQUIRE(h && ring && kernel >= 0 && kernel < K_COUNT && reps >= 1, "fb_qnet_profile_ring: bad argument");
+    FB_REQUIRE(algo != FB_ALGO_PER, "fb_qnet_profile_ring: uniform memories only");
+    Plan p;
+    int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, nullptr, 0.99, loss, nullptr, nullptr, nullptr, &p, ring);
+    if (rc != FB_OK) return rc;
+    p.tick = false;
+    rc = fb_qnet_refresh_planes(h, stream);
+    for (int i = 0; i < reps && rc == FB_OK; i++) rc = run_plan(h, p, kernel, fb_stream(stream));
+    return rc;
 }
 
 int fb_qnet_train_step_rider(fb_qnet_t h, int algo, int B, const uint8_t *s, const uint8_t *a, const float *r, const uint8_t *s2,

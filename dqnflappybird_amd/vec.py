@@ -368,6 +368,22 @@ class QNet:
         L.check(L.lib().fb_qnet_apply_adam(self.h, L.ptr(flat_grad), L.current_stream()), "fb_qnet_apply_adam")
 
 
+def train_from_replay(replay, net, algo, idx, gamma=0.99, flat_grad=None):
+    """replay.gather(idx) + net.train_step(...) without the gathered copies (fb_train_from_replay): the conv trunk reads the sampled
+    transitions' 1-bit frames in the ring directly.  Same results as the two calls (batch < 256; "dqn", "nature", "double").
+    -> (loss f32[1], a u8[B], r f32[B], t u8[B]) on the device."""
+    if replay.prioritized or algo == "per":
+        raise ValueError("train_from_replay is for uniform replay (PER needs the importance weights: use the separate calls)")
+    _dev_check(idx, flat_grad)
+    B, dev = int(idx.numel()), idx.device
+    a = torch.empty(B, dtype=torch.uint8, device=dev); r = torch.empty(B, dtype=torch.float32, device=dev)
+    t = torch.empty(B, dtype=torch.uint8, device=dev); loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    L.check(L.lib().fb_train_from_replay(replay.h, net.h, ALGOS[algo], B, L.ptr(idx), L.ptr(a), L.ptr(r), L.ptr(t), float(gamma),
+                                         L.ptr(loss), None if flat_grad is None else L.ptr(flat_grad), L.current_stream()),
+            "fb_train_from_replay")
+    return loss, a, r, t
+
+
 class TrainSteps:
     """n x (random.sample -> minibatch -> _trainQNetwork) on a uniform memory that is not being pushed to, as one host call
     (fb_train_steps): the separate calls' results, with the next step's random.sample riding in the conv3 backward launch."""

@@ -271,6 +271,8 @@ const char *fb_qnet_kernel_name(int kernel);
  * four launches: the head of the acting forward (fc2 + epsilon-greedy action), random.sample and the Memory append
  * ride inside the env step launch (uniform memory, CPython generator, <= 2048 envs and 2 actions for the head; anything
  * else keeps its own launch), bit-identical to the separate calls.
+ * With >= 256 envs the step skips the gather launch as well: the train step's first kernel reads the sampled
+ * transitions' 1-bit frames in the ring itself (fb_train_from_replay below) -- same results, b->s / b->s2 stay untouched.
  * All pointers [dev], caller owned; nib is the buffer given to fb_env_set_nib_buffer.  train = 0 stops after the
  * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
  * fb_qnet_apply_adam). */
@@ -286,6 +288,17 @@ typedef struct {
 } fb_step_buffers;
 int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo, int batch,
                 float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);
+
+/* fb_replay_gather + fb_qnet_train_step WITHOUT the gathered copies (BrainDQN.py:197-223 from the indices on): the minibatch is
+ * described by its indices, the conv trunk reads the replay's 1-bit frames directly (5 x 800 B per transition instead of writing and
+ * re-reading 51 KB of u8 expansion) and fills a, r, t (u8 / f32 / u8 [batch], [dev] out).  Bit-identical to the two separate calls.
+ * batch <= 256; algo = DQN / NATURE / DOUBLE (a prioritized step needs the importance weights: separate calls); flat_grad as in
+ * fb_qnet_train_step. */
+int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, uint8_t *a, float *r, uint8_t *t,
+                         double gamma, float *loss, float *flat_grad, void *stream);
+/* Measurement aid: kernel `kernel` (ids of fb_qnet_kernel_name) of that step's plan, `reps` times, like fb_qnet_profile_kernel. */
+int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int reps, int algo, int batch, const int64_t *idx, uint8_t *a,
+                           float *r, uint8_t *t, float *loss, void *stream);
 
 /* n_steps x (fb_replay_sample -> fb_replay_gather -> fb_qnet_train_step) on a uniform memory in ONE call, same results: only
  * the first draw and the first gather are launches of their own, the draw of step i + 1 rides in step i's conv3 backward

@@ -293,6 +293,47 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("algo,B", [("dqn", 32), ("nature", 17), ("double", 64), ("double", 256)])
+def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B):
+    """fb_train_from_replay (the conv trunk reads the sampled transitions' 1-bit frames in the ring; no gathered copies) ==
+    fb_replay_gather + fb_qnet_train_step, bit for bit below 256 samples: a / r / t, loss, parameters and Adam slots over several steps, on a ring
+    that has wrapped, with indices at both ends of the deque, right after a target sync and after a stand-alone Adam (stale planes)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, train_from_replay
+    N = 64
+    env, rep = VecGameState(N, seed=3), VecReplay(1500, N)
+    env.observe(); rep.reset(env.frame_bits)
+    rng = np.random.default_rng(0)
+    for _ in range(40):                                   # 2560 transitions through a 1500-slot memory: the ring wraps
+        acts = torch.from_numpy((rng.random(N) < 0.15).astype(np.uint8)).cuda()
+        env.frame_step(acts, want_u8=False)
+        rep.push(env.frame_bits, acts, env.reward, env.terminal)
+    n1, n2 = QNet(max_batch=B), QNet(max_batch=B)
+    for n in (n1, n2):
+        n.init_params(7); n.sync_target()
+    size = len(rep)
+    # B = 256: the separate calls run the large-batch kernels (another summation order in conv2 / conv3), so equal to rounding only
+    same = (lambda x, y: torch.equal(x, y)) if B < 256 else (lambda x, y: torch.allclose(x, y, rtol=2e-4, atol=2e-6))
+    for step in range(6):
+        idx = torch.from_numpy(rng.integers(0, size, B)).cuda()
+        idx[0], idx[1] = 0, size - 1                      # oldest and newest transition
+        s, a, r, s2, t = rep.gather(idx)
+        l1, _, _ = n1.train_step(algo, s, a, r, s2, t, want_aux=False)
+        l2, a2, r2, t2 = train_from_replay(rep, n2, algo, idx)
+        assert torch.equal(a, a2) and torch.equal(r, r2) and torch.equal(t, t2)
+        assert same(l1, l2), (step, l1, l2)
+        if step == 2:
+            n1.sync_target(); n2.sync_target()
+        if step == 3:                                     # a stand-alone Adam leaves the planes stale: the call has to notice
+            g = torch.full((n1.n_params,), 1e-3, device="cuda")
+            n1.apply_adam(g); n2.apply_adam(g)
+    assert same(n1.store_params(), n2.store_params())
+    m1, v1, _ = n1.adam_state(); m2, v2, _ = n2.adam_state()
+    assert same(m1, m2) and same(v1, v2)
+    with pytest.raises(Exception):
+        train_from_replay(rep, n2, algo, torch.zeros(257, dtype=torch.int64, device="cuda"))
+
+
 @pytest.mark.parametrize("N,steps,algo", [(256, 40, "dqn"), (2304, 24, "nature")])
 def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     """The N > 1 hot path at world size 1 (bench.py full_step / VecBrain.step): fb_vec_step(flat_grad = g) followed by
