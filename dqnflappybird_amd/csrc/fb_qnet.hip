@@ -103,51 +103,13 @@ __device__ __forceinline__ void keep(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ float rbf(float x, bool rb) { return rb ? (float)(__bf16)x : x; }
 __device__ __forceinline__ void keep(int &x) { asm volatile("" : "+v"(x)); }
 
-// KH MFMAs: A from a contiguous run of KH floats (or zeros), B from a column with stride bstride
-template <int KH>
-__device__ __forceinline__ void mma_run_col(const float *__restrict__ arun, bool ok, const float *__restrict__ bcol,
-                                            int bstride, f32x16 &acc, bool rb = false) {
-    float a[KH], b[KH];
-#pragma unroll
-    for (int q = 0; q < KH / 4; q++) {
-        const float4 v = reinterpret_cast<const float4 *>(arun)[q];
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int t = 0; t < KH; t++) b[t] = bcol[(size_t)t * bstride];
-#pragma unroll
-    for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
-#pragma unroll
-    for (int t = 0; t < KH; t++) acc = mfma(rbf(a[t], rb), rbf(b[t], rb), acc);
-}
-
-// KH MFMAs with both operands as contiguous runs
-template <int KH>
-__device__ __forceinline__ void mma_run_run(const float *__restrict__ arun, bool ok, const float *__restrict__ brun,
-                                            f32x16 &acc, bool rb = false) {
-    float a[KH], b[KH];
-#pragma unroll
-    for (int q = 0; q < KH / 4; q++) {
-        const float4 v = reinterpret_cast<const float4 *>(arun)[q];
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-        const float4 u = reinterpret_cast<const float4 *>(brun)[q];
-        b[4 * q] = u.x; b[4 * q + 1] = u.y; b[4 * q + 2] = u.z; b[4 * q + 3] = u.w;
-    }
-#pragma unroll
-    for (int t = 0; t < KH; t++) { keep(a[t]); a[t] = ok ? a[t] : 0.f; }
-#pragma unroll
-    for (int t = 0; t < KH; t++) acc = mfma(rbf(a[t], rb), rbf(b[t], rb), acc);
-}
-
 // ================================================================== forward
-// ---- conv1 on the bf16 matrix cores, exactly.
-// conv1's input is u8 (in practice 0 / 255): every u8 value is exact in bf16 (8 significant bits).  Each fp32
-// weight is split into three bf16 parts w = hi + mid + lo (8 + 8 + 8 mantissa bits, exact), so
-// sum_k x_k * w_k = sum_k x_k*hi_k + x_k*mid_k + x_k*lo_k with every product exact in fp32 and fp32
-// accumulation inside v_mfma_f32_32x32x16_bf16 -- three matrix instructions at 16x the fp32-MFMA rate, i.e.
-// 5.3x fewer matrix cycles than the fp32-input instruction, and they leave the vector ALU free for the
-// u8 -> bf16 conversion.  K = 256 = 8 ky x 2 chunks of 16 (4 pixels x 4 frames = 16 contiguous bytes).
-// The split weights live in w1s[part][ky][kq][h][co][8] (bf16), refreshed whenever the parameters change.
+// ---- conv1 on the fp16 matrix cores, exactly.
+// conv1's input is u8 (in practice 0 / 255): every u8 value is exact in fp16.  Each fp32 weight is carried as two fp16 numbers
+// w = h + l / 4096 (split2x2 below), so sum_k x_k * w_k = sum_k x_k*h_k + (sum_k x_k*l_k) / 4096 with every product exact in the
+// fp32 accumulation inside v_mfma_f32_32x32x16_f16 -- two matrix instructions per 16 k, and they leave the vector ALU free for the
+// u8 -> fp16 conversion.  K = 256 = 8 ky x 2 chunks of 16 (4 pixels x 4 frames = 16 contiguous bytes).
+// The split weights live in w1s[part][ky][kq][h][co][8] (fp16), refreshed whenever the parameters change.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rn(float x) {
@@ -1742,45 +1704,6 @@ __global__ __launch_bounds__(512) void fc1_bwd2_kernel(Bw1Args L) {
 }
 
 // ================================================================== backward
-// dW_fc1[k][n] = sum_b h3[b][k] * dhf[b][n]: one wave per 32x32 tile, reduction over the batch
-__device__ __forceinline__ void fc1_dw_body(int blk, const float *__restrict__ h3, const float *__restrict__ dhf,
-                                            float *__restrict__ grad, int B, int FC, bool rb) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int nt_n = FC / 32, tile = blk * 8 + wave;
-    if (tile >= 50 * nt_n) return;
-    const int kt = tile / nt_n, nt = tile - kt * nt_n;
-    f32x16 acc = {0};
-#pragma unroll 4
-    for (int t = 0; t < (B + 1) / 2; t++) {
-        const int b = 2 * t + hl;
-        const int bc = b < B ? b : 0;
-        const float a = h3[(size_t)bc * 1600 + kt * 32 + i], bb = dhf[(size_t)bc * FC + nt * 32 + j];
-        acc = mfma(b < B ? rbf(a, rb) : 0.f, b < B ? rbf(bb, rb) : 0.f, acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) grad[OFF_WF1 + (size_t)(kt * 32 + drow(r, lane)) * FC + nt * 32 + j] = acc[r];
-}
-
-// dh3[b][k] = (h3 > 0) * sum_n dhf[b][n] * W_fc1[k][n]; 8 waves split n
-__device__ __forceinline__ void fc1_dx_body(int blk, float *red, const float *__restrict__ params, const float *__restrict__ h3,
-                                            const float *__restrict__ dhf, float *__restrict__ dh3, int B, int FC, bool rb) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31, j = lane & 31;
-    const int mt = blk / 50, kt = blk - mt * 50;
-    const int m = mt * 32 + i;
-    const bool ok = m < B;
-    const int kh = FC / 16, nbeg = wave * (FC / 8) + hl * kh;
-    const float *arun = dhf + (size_t)(ok ? m : 0) * FC + nbeg;
-    const float *brun = params + OFF_WF1 + (size_t)(kt * 32 + j) * FC + nbeg;
-    f32x16 acc = {0};
-    int c = 0;
-    for (; c + 32 <= kh; c += 32) mma_run_run<32>(arun + c, ok, brun + c, acc, rb);
-    for (; c < kh; c += 8) mma_run_run<8>(arun + c, ok, brun + c, acc, rb);
-    reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
-        const size_t o = (size_t)mr * 1600 + kt * 32 + j;
-        dh3[o] = h3[o] > 0.f ? v : 0.f;
-    });
-}
-
 // conv weight (+ bias) gradients: dW[(cell, ci)][co] = sum_m X[m @ cell][ci] * dY[m][co], db[co] = sum_m dY[m][co].
 // One workgroup = one 32(ci) x 32(co) tile of one kernel cell; its 8 waves and the gridDim.y slabs split
 // the reduction over output pixels m (each wave: one or two chunks of 16 MFMAs whose 32 operand loads are
@@ -1986,15 +1909,102 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
     }
 }
 
-// ---- merged backward launches: the weight-gradient tiles and the data-gradient tiles of one layer are
-// independent, so they share one launch (the first n_dx workgroups run the dX body, the rest the dW body):
-// three kernel boundaries fewer per step and the two latency chains overlap.
-__global__ __launch_bounds__(512) void fc1_bwd_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
-                                                      const float *__restrict__ dhf, float *__restrict__ dh3,
-                                                      float *__restrict__ grad, int B, int FC, int rb) {
+// ---- fc1 backward of a LARGE batch (256 samples; small ones: fc1_bwd2_kernel) on the fp16 matrix instruction, one wave per 32 x 32
+// tile, operands split into two fp16 planes (NS = 3; NS = 1: rounded to bf16, one product) on the fly from fp32 rows that stay L2 resident
+// (dhf 0.5 MB, h3 1.6 MB, W_fc1 3.3 MB) -- no staging, no reduction between waves, and the loads of four k-steps in flight while the
+// previous four are in the MFMAs.  (The fp32-input MFMA version of this launch took 35 us at B = 256: two scalar loads in front of
+// every 64-cycle MFMA, 32 dependent round trips per wave.)
+//   data gradient    dh3[b][i] = (h3[b][i] > 0) * sum_n dhf[b][n] * W_fc1[i][n]: both operands are K-contiguous rows, 8 floats per lane
+//   weight gradient  dW[i][n]  = sum_b h3[b][i] * dhf[b][n]: the reduction runs over samples, a lane gathers its 8 k-values with 8
+//                    loads (each one coalesced across the 32 lanes of a half)
+struct FragF { float4 a0, a1, b0, b1; };                // one k-step of one lane: 8 values of each operand
+template <int NS>
+__device__ __forceinline__ void mma_frag(const FragF f, f32x16 &acc, f32x16 &acl) {
+    if constexpr (NS == 3) {
+        uint4 ah, al, bh, bl;
+        split2x2(f.a0.x, f.a0.y, ah.x, al.x); split2x2(f.a0.z, f.a0.w, ah.y, al.y); split2x2(f.a1.x, f.a1.y, ah.z, al.z); split2x2(f.a1.z, f.a1.w, ah.w, al.w);
+        split2x2(f.b0.x, f.b0.y, bh.x, bl.x); split2x2(f.b0.z, f.b0.w, bh.y, bl.y); split2x2(f.b1.x, f.b1.y, bh.z, bl.z); split2x2(f.b1.z, f.b1.w, bh.w, bl.w);
+        acl = mfma_h(ah, bl, acl);
+        acl = mfma_h(al, bh, acl);
+        acc = mfma_h(ah, bh, acc);
+    } else {
+        uint4 ah, bh; uint32_t m_, l_;
+        split3x2(f.a0.x, f.a0.y, ah.x, m_, l_); split3x2(f.a0.z, f.a0.w, ah.y, m_, l_); split3x2(f.a1.x, f.a1.y, ah.z, m_, l_); split3x2(f.a1.z, f.a1.w, ah.w, m_, l_);
+        split3x2(f.b0.x, f.b0.y, bh.x, m_, l_); split3x2(f.b0.z, f.b0.w, bh.y, m_, l_); split3x2(f.b1.x, f.b1.y, bh.z, m_, l_); split3x2(f.b1.z, f.b1.w, bh.w, m_, l_);
+        acc = mfma_b(ah, bh, acc);
+    }
+}
+// One workgroup per 32 x 32 tile, its 8 waves split the reduction (K = FC units for the data gradient, K = B samples for the weight
+// gradient) and add their partial tiles through LDS in wave order (reduce_rows): a wave's chain is ONE group of loads, all in flight
+// together, and a handful of MFMAs.  (One wave per tile walked 32 k-steps with a prefetch distance of one: 20 us at B = 256, the same in
+// bf16 -- latency, not arithmetic; the fp32-MFMA kernel before that took 35 us.)
+// KX / KW: k-steps per wave of the two roles as compile-time constants (FC / 128, B / 128), 0 = run-time counts.
+template <int NS, int KX, int KW>
+__global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
+                                                          const float *__restrict__ dhf, float *__restrict__ dh3,
+                                                          float *__restrict__ grad, int B, int FC) {
     __shared__ float red[8 * 16 * 64];
-    if ((int)blockIdx.x < n_dx) fc1_dx_body(blockIdx.x, red, params, h3, dhf, dh3, B, FC, rb);
-    else fc1_dw_body(blockIdx.x - n_dx, h3, dhf, grad, B, FC, rb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, r = lane & 31;
+    const int tile = blockIdx.x;
+    f32x16 acc = {0}, acl = {0};
+    if (tile < n_dx) {
+        const int mt = tile / 50, it = tile - mt * 50, m = mt * 32 + r;
+        const int per = KX ? KX : FC / 128, k0 = wave * per;
+        const float4 *pa = reinterpret_cast<const float4 *>(dhf + (size_t)(m < B ? m : 0) * FC + 8 * hl) + k0 * 4;
+        const float4 *pb = reinterpret_cast<const float4 *>(params + OFF_WF1 + (size_t)(it * 32 + r) * FC + 8 * hl) + k0 * 4;
+        auto ld = [&](int ks) { return FragF{pa[ks * 4], pa[ks * 4 + 1], pb[ks * 4], pb[ks * 4 + 1]}; };      // k-step k0 + ks: units 16 (k0 + ks) + 8 hl ..
+        if constexpr (KX > 0) {
+            FragF f[KX];
+#pragma unroll
+            for (int q = 0; q < KX; q++) f[q] = ld(q);
+#pragma unroll
+            for (int q = 0; q < KX; q++) mma_frag<NS>(f[q], acc, acl);
+        } else {
+            for (int q = 0; q < per; q++) mma_frag<NS>(ld(q), acc, acl);
+        }
+        if constexpr (NS == 3) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+        }
+        reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
+            const size_t o = (size_t)mr * 1600 + it * 32 + r;
+            dh3[o] = h3[o] > 0.f ? v : 0.f;
+        });
+        return;
+    }
+    const int t = tile - n_dx, nt_n = FC / 32;
+    const int it = t / nt_n, nt = t - it * nt_n;
+    const float *pa = h3 + it * 32 + r, *pb = dhf + nt * 32 + r;
+    const int per = KW ? KW : ((B + 15) / 16 + 7) / 8, k0 = wave * per;
+    auto ld = [&](int ks) {                              // k-step k0 + ks: samples 16 (k0 + ks) + 8 hl .. + 7 (past the batch: row 0, zeroed)
+        const int b0 = 16 * (k0 + ks) + 8 * hl;
+        float a[8], bb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool ok = b0 + j < B;
+            const size_t bc = ok ? b0 + j : 0;
+            const float x = pa[bc * 1600], y = pb[bc * FC];
+            a[j] = ok ? x : 0.f; bb[j] = ok ? y : 0.f;
+        }
+        return FragF{make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]), make_float4(bb[0], bb[1], bb[2], bb[3]),
+                     make_float4(bb[4], bb[5], bb[6], bb[7])};
+    };
+    if constexpr (KW > 0) {
+        FragF f[KW];
+#pragma unroll
+        for (int q = 0; q < KW; q++) f[q] = ld(q);
+#pragma unroll
+        for (int q = 0; q < KW; q++) mma_frag<NS>(f[q], acc, acl);
+    } else {
+        for (int q = 0; q < per; q++) mma_frag<NS>(ld(q), acc, acl);
+    }
+    if constexpr (NS == 3) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+    }
+    reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
+        grad[OFF_WF1 + (size_t)(it * 32 + row32) * FC + nt * 32 + r] = v;
+    });
 }
 
 // TF ApplyAdam on four consecutive parameters (the one definition both Adam paths use)
@@ -2633,7 +2643,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (z1 > h->zmax) z1 = h->zmax;
         const int z2 = z3;
         const size_t ss = CONV_PARAMS;
-        const int ndx1 = ((B + 31) / 32) * 50, ndw1 = (50 * (FC / 32) + 7) / 8;
+        const int ndx1 = ((B + 31) / 32) * 50;
         if (fk) { FB_K(K_FC1_BWD) {
             Bw1Args L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.stot = stot; L.n_dx = ndx1; L.off = h->off;
@@ -2643,7 +2653,18 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
             L.adam = h->adam; L.tick = p.tick; L.rb = rbt;
             hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7), dim3(512), 0, st, L);
-        } } else FB_K(K_FC1_BWD) hipLaunchKernelGGL(fc1_bwd_kernel, dim3(ndx1 + ndw1), dim3(512), 0, st, ndx1, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, rbt);
+        } } else FB_K(K_FC1_BWD) {
+            const int ndx = ((B + 31) / 32) * 50, ntile = ndx + 50 * (FC / 32);        // one workgroup per 32 x 32 tile, data-gradient tiles first
+            const dim3 gb(ntile);
+            const bool std_shape = FC == 512 && B == 256;      // the shapes this path sees (MAXTB = 256): fully unrolled instantiation
+            if (h->nsplit_train == 3) {
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+            } else {
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+            }
+        }
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
         const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
