@@ -1116,19 +1116,21 @@ struct LossArgs {
     AdamDev *adam; int tick;
 };
 
-// grid = FC / 64 workgroups.  Every workgroup recomputes the B targets (cheap), workgroup 0 also publishes
+// (Large batches only: small ones get all of this inside fc1_bwd2_kernel.)
+// grid = FC / 16 workgroups.  Every workgroup recomputes the B targets (cheap), workgroup 0 also publishes
 // loss / abs_err / y, the output-bias gradients and the Adam tick.  Thread (jl, bg) owns unit j and every
-// 4th sample; the 4 partial sums per unit are added in a fixed order.
+// 16th sample; the 16 partial sums per unit are added in a fixed order.  (64 units x 4 sample groups per workgroup
+// meant 8 workgroups, each thread walking 64 samples in 8 dependent rounds of loads: 13.8 us at B = 256.)
 // ONE round trip to memory: the unit's parameters and the fc1 partial sums of its first 8 samples (all of them at
 // B <= 32) are requested at the top, together with the Q values / rewards / actions of the target computation --
 // nothing is loaded behind the barrier, and no load sits under a branch (clamped addresses + selects; AT = the
 // number of actions at compile time, MAXA = read it from L.A).
 template <int AT>
-__device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[MAXA], float *dv, float *lterm, float (*part)[64][MAXA + 2]) {
+__device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[MAXA], float *dv, float *lterm, float (*part)[16][MAXA + 2]) {
     const int tid = threadIdx.x, B = L.B, A = AT == MAXA ? L.A : AT;
     const bool lead = blockIdx.x == 0;
     const float *P = L.params;
-    const int jl = tid & 63, bg = tid >> 6, jj = blockIdx.x * 64 + jl;
+    const int jl = tid & 15, bg = tid >> 4, jj = blockIdx.x * 16 + jl;
     // ---- everything this thread needs from memory
     float gw[AT], wrow[AT], gv = 0.f, gb = 0.f;
 #pragma unroll
@@ -1138,7 +1140,7 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
     float hv[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-        const int b = bg + 4 * u;
+        const int b = bg + 16 * u;
         hv[u] = fc1_out(L.hf, L.stot, L.FC, b < B ? b : bg, jj, bias, L.nks);
     }
     const int tb = tid < B ? tid : 0;                            // threads past the batch recompute sample 0 and store nothing
@@ -1218,11 +1220,11 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
     if (lead && tid == 128 && L.dueling) { float s = 0.f; for (int b = 0; b < B; b++) s += dv[b]; L.grad[L.off.bv] = s; }
     // 8 samples per round: their 8 x nks partial sums are requested together (the first round's at the top of the kernel);
     // the arithmetic and its order per sample are unchanged
-    for (int b0 = bg; b0 < B; b0 += 32) {
+    for (int b0 = bg; b0 < B; b0 += 128) {
         if (b0 != bg) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int b = b0 + 4 * u;
+                const int b = b0 + 16 * u;
                 hv[u] = fc1_out(L.hf, L.stot, L.FC, b < B ? b : bg, jj, bias, L.nks);
             }
 #pragma unroll
@@ -1230,7 +1232,7 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int b = b0 + 4 * u;
+            const int b = b0 + 16 * u;
             if (b < B) {
                 const float h = hv[u];
                 float d = dv[b] * wvj;
@@ -1248,11 +1250,17 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
     part[bg][jl][MAXA] = gv; part[bg][jl][MAXA + 1] = gb;
     __syncthreads();
     if (bg == 0) {
+        auto total = [&](int c) {
+            float v = part[0][jl][c];
+#pragma unroll
+            for (int g = 1; g < 16; g++) v += part[g][jl][c];
+            return v;
+        };
 #pragma unroll
         for (int a = 0; a < AT; a++)
-            if (a < A) L.grad[L.off.wq + jj * A + a] = ((part[0][jl][a] + part[1][jl][a]) + part[2][jl][a]) + part[3][jl][a];
-        if (L.dueling) L.grad[L.off.wv + jj] = ((part[0][jl][MAXA] + part[1][jl][MAXA]) + part[2][jl][MAXA]) + part[3][jl][MAXA];
-        L.grad[L.off.bf1 + jj] = ((part[0][jl][MAXA + 1] + part[1][jl][MAXA + 1]) + part[2][jl][MAXA + 1]) + part[3][jl][MAXA + 1];
+            if (a < A) L.grad[L.off.wq + jj * A + a] = total(a);
+        if (L.dueling) L.grad[L.off.wv + jj] = total(MAXA);
+        L.grad[L.off.bf1 + jj] = total(MAXA + 1);
     }
 }
 
@@ -1260,7 +1268,7 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     __shared__ float dadv[MAXTB][MAXA];
     __shared__ float dv[MAXTB];
     __shared__ float lterm[MAXTB];
-    __shared__ float part[4][64][MAXA + 2];
+    __shared__ float part[16][16][MAXA + 2];
     if (L.A == 2) loss_head_body<2>(L, dadv, dv, lterm, part);
     else loss_head_body<MAXA>(L, dadv, dv, lterm, part);
 }
@@ -2213,16 +2221,22 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
 // walk up to 7 chunks one after the other (94 us at B = 256).  It is cut into up to 4 x 64 sub-slabs instead (one chunk
 // per wave again) and this kernel folds groups of 4 into the 64 slabs the Adam kernel sums, in a fixed order.
-constexpr int FOLD = 4, CONV1_PARAMS = OFF_W2;       // W_conv1 + b_conv1 open a slab
-__global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, float *__restrict__ slabs, size_t slab_stride) {
+constexpr int CONV1_PARAMS = OFF_W2;       // W_conv1 + b_conv1 open a slab
+__global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, int fold, float *__restrict__ slabs, size_t slab_stride) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (idx >= CONV1_PARAMS) return;
     float v = 0.f;
+    for (int q0 = 0; q0 < fold; q0 += 4) {               // four loads in flight at a time, added in slab order
+        float x[4];
 #pragma unroll
-    for (int q = 0; q < FOLD; q++) {
-        const int z = s * FOLD + q;
-        const float x = sub[(size_t)(z < nsub ? z : 0) * CONV1_PARAMS + idx];
-        v += z < nsub ? x : 0.f;
+        for (int q = 0; q < 4; q++) {
+            const int z = s * fold + q0 + q;
+            const bool ok = q0 + q < fold && z < nsub;
+            x[q] = sub[(size_t)(ok ? z : 0) * CONV1_PARAMS + idx];
+            x[q] = ok ? x[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) v += x[q];
     }
     slabs[s * slab_stride + idx] = v;
 }
@@ -2361,7 +2375,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->params[0], nb); alloc((void **)&h->params[1], nb);
     alloc((void **)&h->adam_m, nb); alloc((void **)&h->adam_v, nb); alloc((void **)&h->grad, nb);
     alloc((void **)&h->slabs, sizeof(float) * (size_t)h->zmax * CONV_PARAMS);
-    if (max_batch > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)FOLD * h->zmax * CONV1_PARAMS);
+    if (2 * max_batch > h->zmax) alloc((void **)&h->slabs1, sizeof(float) * (size_t)2 * (max_batch < MAXTB ? max_batch : MAXTB) * CONV1_PARAMS);      // two sub-slabs per sample
     alloc((void **)&h->adam, sizeof(AdamDev));
     alloc((void **)&h->w1s[0], 3 * 8192 * 2); alloc((void **)&h->w1s[1], 3 * 8192 * 2);
     const size_t wsp_bytes = (size_t)wsp_total(fc_width) * sizeof(uint4);
@@ -2635,7 +2649,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             // (at most one tick per Adam update: guarded on the device by AdamDev::ticks / applies)
             if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
             L.adam = h->adam; L.tick = p.tick;
-            hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 64), dim3(256), 0, st, L);
+            hipLaunchKernelGGL(loss_head_kernel, dim3(FC / 16), dim3(256), 0, st, L);
         }
         // slabs: one chunk of <= 16 MFMAs (32 output pixels) per wave where the slab budget allows it
         int z3 = (B * 25 + 255) / 256, z1 = (B * 400 + 255) / 256;
@@ -2673,9 +2687,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         if (p.sample_rider) srider = *p.sample_rider;
         {
             // [data-gradient chain per sample + conv3 dW + W_fc1's Adam] and [conv2 dW + conv1 dW] (see conv_bx_kernel)
-            const int nsp1 = 2 * B <= h->zmax ? 2 : 1;
-            const bool fold1 = B > h->zmax;              // more conv1 slabs than the common set holds: 4 : 1 folding afterwards
-            z1 = fold1 ? (B + FOLD - 1) / FOLD : nsp1 * B;
+            // conv1's weight gradient: two workgroups per sample, each with its own slab (2 B slabs); more than zmax of them are written
+            // to the sub-slab buffer and folded into zmax slabs afterwards, in a fixed order
+            const bool fold1 = 2 * B > h->zmax;
+            const int fold = (2 * B + h->zmax - 1) / h->zmax;
+            z1 = fold1 ? (2 * B + fold - 1) / fold : 2 * B;
             const int n_adam5 = (span1 - span0 + 511) / 512;
             const BxArgs bx{h->dh3, h->h2, h->p1, h->dh2, h->dp1, h->wsp[0] + wsp_w3t(FC), h->wsp[0] + wsp_w2t(FC)};
             FB_K(K_CONV3_BWD) {
@@ -2685,13 +2701,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             }
             FB_K(K_CONV2_BWD) {
                 const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
-                if (nsp1 == 2 && p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt, dr);
-                else if (nsp1 == 2) hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, h->slabs, ss, rbt, dr);
-                else if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<1, true>), dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
-                                                    fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt, dr);
-                else hipLaunchKernelGGL((conv_dw21_kernel<1, false>), dim3(34 * z2 + B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss,
-                                        fold1 ? h->slabs1 : h->slabs, fold1 ? (size_t)CONV1_PARAMS : ss, rbt, dr);
-                if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, B, h->slabs, ss);
+                float *s1 = fold1 ? h->slabs1 : h->slabs;
+                const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
+                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
+                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
+                if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
             }
         }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
