@@ -355,8 +355,9 @@ def main():
         # B read + written per transition) -- the ring stores a frame as 800 B of bits and shares frames between s and s', so the launch
         # really moves far less: `pmc_*` price the HBM bytes the PMC counters saw (profiles/traffic.json).  The north-star ">= 40 % of the
         # HBM roofline" is met on the logical figure from B = 256 up and on the PMC figure at B = 4096; at B = 32 the launch is 1 us of
-        # traffic inside a ~3.5 us dependent launch: latency bound.
-        roofline["replay_gather"] = {}
+        # traffic inside a ~3.5 us dependent launch: latency bound.  The measured loop itself no longer launches a
+        # gather at all: its train step reads the sampled transitions' bits in the ring directly (4 KB per transition; `ingest` below).
+        roofline["replay_gather"] = {"in_loop": "none: the conv trunk kernel reads 4 x 800 B of frame bits per state from the ring (conv23_t_kernel<ring>)"}
         for b, n in (("B=32", "gather_kernel<false>[B=32]"), ("B=256", "gather_kernel<false>[B=256]"), ("B=4096", "gather_kernel<false>[B=4096]")):
             g_ = {f: gk[n][f] for f in ("achieved", "peak", "unit", "frac", "traffic", "us")}
             g_["basis"] = "logical bytes (SURVEY 8d: 102 417 B per sampled transition)"

@@ -2537,8 +2537,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     int maxc = 0, total = 0;
     for (int z = 0; z < p.ns; z++) { if (p.sl.s[z].count > maxc) maxc = p.sl.s[z].count; total += p.sl.s[z].count; }
     // >= 256 samples in a slice: thousands of tiles, one wave per tile (no K split); below: K split over waves
-    static const int small_env = getenv("FB_SMALL") ? atoi(getenv("FB_SMALL")) : 0;
-    const bool big = maxc >= 256 && !(small_env && p.train);
+    const bool big = maxc >= 256;
     // >= 256 states per slice: the LDS-staged two-plane-fp16 kernels (conv1_sp / conv23_sp / fc1_sp).  Forward-only plans take
     // them with one slice; TRAINING plans run them in passes, one per run of consecutive slices that go through the same net
     // (DQN: s and s' in one pass; Nature / PER: s online, s' target; Double: s, s' online + s' target), with fp32 side outputs
