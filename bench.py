@@ -114,10 +114,21 @@ def main():
     # gather -> train; the same launches as the separate calls, without the interpreter between them)
     one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad)
 
+    # N > 1: one all-reduce of the flat gradient per step (sum loss, BrainDQN.py:162 -> plain sum).  FB_DP_OVERLAP=1 issues it in two
+    # pieces instead (dist.OverlappedAllReduce: the W_fc1 / head part, final after the fc1 backward launch, on a side stream while the
+    # conv backward runs).  Off by default: through torch.distributed every collective costs two cross-stream hops, and at world size 1
+    # -- all this build could measure -- the split step is 31 us slower than the plain one (tools/time_dp_step.py).
+    from dqnflappybird_amd.dist import OverlappedAllReduce
+    want_overlap = os.environ.get("FB_DP_OVERLAP", "0") == "1"
+    reduce_grad = OverlappedAllReduce(net, grad, mean_loss=False) if world > 1 and backend == "nccl" and want_overlap else None
+
     def full_step(step):
         one_step(eps, seed=seed + rank, step=step)
         if world > 1:
-            dist.all_reduce(grad)                           # sum loss (BrainDQN.py:162) -> plain sum
+            if reduce_grad is not None:
+                reduce_grad()
+            else:
+                dist.all_reduce(grad)
             net.apply_adam(grad)
 
     def timed(fn, k, first=0):

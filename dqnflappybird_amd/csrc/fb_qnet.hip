@@ -2343,6 +2343,7 @@ struct fb_qnet {
     float *p1, *h2, *h3, *hf, *q;
     float *qpart;                    // small-batch training: per 16-unit tile shares of the head, [FC/16][S][A + 1]
     unsigned long long *ring_fo;     // ring-fed training: the four frame offsets of every sample's state s, [max_batch][4]
+    hipEvent_t grad_ev;              // fb_qnet_set_grad_event: recorded behind the fc1 backward launch of a gradient-exporting step, or NULL
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
     int zmax;
@@ -2678,6 +2679,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
             }
         }
+        // data-parallel path: from here on G[CONV_PARAMS ..) -- W_fc1, b_fc1, the head: 91 % of the bytes -- is final; the caller's side
+        // stream can start reducing it while the conv backward below still runs (fb_qnet_set_grad_event)
+        if (!p.apply_adam && h->grad_ev && only < 0) FB_CHECK_HIP(hipEventRecord(h->grad_ev, st));
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
         const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
@@ -2801,6 +2805,14 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
+
+extern "C" int fb_qnet_set_grad_event(fb_qnet_t h, void *event) {
+    FB_REQUIRE(h, "fb_qnet_set_grad_event: NULL handle");
+    h->grad_ev = (hipEvent_t)event;
+    return FB_OK;
+}
+
+extern "C" int64_t fb_qnet_grad_split(fb_qnet_t h) { return h ? (int64_t)CONV_PARAMS : 0; }
 
 extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
     FB_REQUIRE(h, "fb_qnet_sync_target: NULL handle");

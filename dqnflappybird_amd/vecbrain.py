@@ -39,6 +39,14 @@ class HipVecBackend:
         import torch
         return torch.zeros(n, dtype=torch.float32, device="cuda")
 
+    def reducer(self, net, flat_grad, mean_loss):
+        """-> callable that all-reduces flat_grad over the ranks: one collective; with FB_DP_OVERLAP=1 two, the large one overlapped
+        with the conv backward (dist.OverlappedAllReduce -- off by default, see its docstring)"""
+        import os
+        if os.environ.get("FB_DP_OVERLAP", "0") == "1":
+            return fdist.OverlappedAllReduce(net, flat_grad, mean_loss)
+        return lambda: fdist.allreduce_gradients(flat_grad, mean_loss)
+
 
 class VecBrain:
     def __init__(self, n_envs, algo="dqn", arch="plain", batch=32, capacity=1_000_000, fc_width=512, seed=0,
@@ -63,6 +71,11 @@ class VecBrain:
                 fdist.broadcast_params(flat, src=0)
                 self.net.load_params(flat, which)
         self.grad = be.zeros(self.net.n_params) if world > 1 else None
+        # one all-reduce of the flat gradient per train step (the HIP backend can split it in two: dist.OverlappedAllReduce)
+        self.reduce = None
+        if self.grad is not None:
+            mk = getattr(be, "reducer", None)
+            self.reduce = mk(self.net, self.grad, MEAN_LOSS[algo]) if mk else (lambda: fdist.allreduce_gradients(self.grad, MEAN_LOSS[algo]))
         self.timeStep = 0
         self.onlineTimeStep = 0
         self.nib = self.env.track_state()                    # currentState of every env, maintained by the env kernel
@@ -85,7 +98,7 @@ class VecBrain:
         loss, abs_err, _ = self.net.train_step(self.algo, s, a, r, s2, t, isw=isw, gamma=self.gamma, flat_grad=self.grad,
                                                want_aux=self.algo == "per")
         if self.grad is not None:
-            fdist.allreduce_gradients(self.grad, MEAN_LOSS[self.algo])
+            self.reduce()
             self.net.apply_adam(self.grad)
         if self.algo == "per":
             self.replay.update_priorities(idx, abs_err=abs_err)
@@ -101,7 +114,7 @@ class VecBrain:
                 self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
             if training:
                 if self.grad is not None:
-                    fdist.allreduce_gradients(self.grad, MEAN_LOSS[self.algo])
+                    self.reduce()
                     self.net.apply_adam(self.grad)
                 self.last_loss = self.one_step.loss
             self.timeStep += 1

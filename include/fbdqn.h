@@ -254,6 +254,13 @@ int fb_qnet_train_step(fb_qnet_t h, int algo, int batch, const uint8_t *s, const
                        const uint8_t *s2, const uint8_t *t, const float *isw, double gamma, float *loss,
                        float *abs_err, float *q_target, float *flat_grad, void *stream);
 int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *stream);
+/* Data parallel, all-reduce off the critical path: a step that exports its gradient (flat_grad != NULL; fb_qnet_train_step,
+ * fb_vec_step, fb_train_from_replay) records `event` (a hipEvent_t, or NULL to switch this off) on its stream right behind the
+ * fc1 backward launch.  From that point flat_grad[fb_qnet_grad_split() ..) -- W_fc1, b_fc1 and the head, 91 % of the bytes -- is
+ * final: reduce it on a side stream that waits for the event while the conv backward (3 more launches) still runs, reduce the
+ * small front part [0, fb_qnet_grad_split()) on the step's stream afterwards, join, fb_qnet_apply_adam. */
+int fb_qnet_set_grad_event(fb_qnet_t h, void *event);
+int64_t fb_qnet_grad_split(fb_qnet_t h);
 int fb_qnet_sync_target(fb_qnet_t h, void *stream);
 /* Measurement aid (bench.py roofline): re-launch ONE kernel of the train-step plan `reps` times on
  * `stream` with the geometry the real step uses, on the workspace a preceding fb_qnet_train_step

@@ -371,6 +371,61 @@ def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
 
 
+def test_overlapped_all_reduce_equals_the_plain_data_parallel_step(torch_cuda):
+    """dist.OverlappedAllReduce (the gradient's W_fc1 / head part reduced on a side stream that waits for the event fb_vec_step records
+    behind its fc1 backward launch, the conv part on the step's stream, then a join) == one all-reduce of the whole vector, through a
+    real one-rank RCCL group: actions, indices, loss step by step, parameters and Adam slots at the end.  Also checks that the event
+    really sits where the header says: the side stream's copy of the tail, taken at the event, already holds the final values."""
+    torch = torch_cuda
+    import os
+    import torch.distributed as tdist
+    from dqnflappybird_amd.dist import OverlappedAllReduce
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    N, B, steps = 512, 32, 24
+    created = not tdist.is_initialized()
+    if created:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        def make():
+            env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+            rep.seed(9, "cpython"); net.init_params(3, which=0); net.init_params(4, which=1)
+            env.track_state(); env.observe(); rep.reset(env.frame_bits)
+            grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda")
+            return env, rep, net, grad, VecStep(env, rep, net, B, "nature", flat_grad=grad)
+
+        e1, r1, n1, g1, plain = make()
+        e2, r2, n2, g2, over = make()
+        red = OverlappedAllReduce(n2, g2, mean_loss=True, force=True)
+        assert red.on and red.tail.numel() > 10 * red.front.numel()
+        snap = torch.zeros_like(red.tail)
+        for step in range(steps):
+            train = step >= 8
+            a1 = plain(0.05, seed=1, step=step, train=train)
+            if train:
+                tdist.all_reduce(g1)
+                n1.apply_adam(g1)
+            a2 = over(0.05, seed=1, step=step, train=train)
+            if train:
+                red.side.wait_event(red.event)
+                with torch.cuda.stream(red.side):
+                    snap.copy_(red.tail)                      # what a side stream sees AT the event
+                red()
+                n2.apply_adam(g2)
+                torch.cuda.current_stream().wait_stream(red.side)
+                assert torch.equal(snap, g1[red.front.numel():]), step
+            assert torch.equal(a1, a2), step
+            if train:
+                assert torch.equal(plain.idx, over.idx) and torch.equal(plain.loss, over.loss), step
+        assert torch.equal(n1.store_params(), n2.store_params())
+        (m1, v1, p1), (m2, v2, p2) = n1.adam_state(), n2.adam_state()
+        assert torch.equal(m1, m2) and torch.equal(v1, v2) and np.array_equal(p1, p2)
+        red.close()
+    finally:
+        if created:
+            tdist.destroy_process_group()
+
+
 def test_graph_replayed_train_steps_refresh_the_acting_weights(torch_cuda):
     """A train step replayed from a captured hipGraph changes the parameters without the host handle noticing: the acting
     forward on >= 256 states (bf16 hi/mid/lo split of the weights) must still re-split them.  Staleness is decided on the
