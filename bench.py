@@ -111,20 +111,22 @@ def main():
             net.train_step("dqn", s, a, r, s2, t, want_aux=False)
 
     # the whole step as one host call (fb_vec_step: act on the nibble states -> env -> store + random.sample ->
-    # gather -> train; the same launches as the separate calls, without the interpreter between them)
-    one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad)
-
-    # N > 1: one all-reduce of the flat gradient per step (sum loss, BrainDQN.py:162 -> plain sum).  FB_DP_OVERLAP=1 issues it in two
-    # pieces instead (dist.OverlappedAllReduce: the W_fc1 / head part, final after the fc1 backward launch, on a side stream while the
-    # conv backward runs).  Off by default: through torch.distributed every collective costs two cross-stream hops, and at world size 1
-    # -- all this build could measure -- the split step is 31 us slower than the plain one (tools/time_dp_step.py).
-    from dqnflappybird_amd.dist import OverlappedAllReduce
+    # train from the ring; the same launches as the separate calls, without the interpreter between them).
+    # N > 1: fb_vec_step_dp -- the same step exporting its gradient, the all-reduce (sum loss, BrainDQN.py:162 -> plain sum) through the
+    # library's own RCCL communicator in two pieces (W_fc1 / head part on a side stream behind the fc1 backward launch, conv part on the
+    # step's stream) and Adam, still one host call.  FB_DP_NATIVE=0 falls back to torch.distributed's all-reduce between fb_vec_step
+    # and fb_qnet_apply_adam (FB_DP_OVERLAP=1: in two pieces, dist.OverlappedAllReduce).
+    from dqnflappybird_amd.dist import NativeDP, OverlappedAllReduce
+    native = None
+    if world > 1 and backend == "nccl" and os.environ.get("FB_DP_NATIVE", "1") != "0":
+        native = NativeDP(rank, world)
+    one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad, dist=native)
     want_overlap = os.environ.get("FB_DP_OVERLAP", "0") == "1"
-    reduce_grad = OverlappedAllReduce(net, grad, mean_loss=False) if world > 1 and backend == "nccl" and want_overlap else None
+    reduce_grad = OverlappedAllReduce(net, grad, mean_loss=False) if world > 1 and backend == "nccl" and want_overlap and native is None else None
 
     def full_step(step):
         one_step(eps, seed=seed + rank, step=step)
-        if world > 1:
+        if world > 1 and native is None:
             if reduce_grad is not None:
                 reduce_grad()
             else:
@@ -427,11 +429,15 @@ def main():
                        "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
                        "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
                        "train_leg": "fb_train_steps(10) in one hipGraph" if graph_used else "eager",
-                       "parallelism": f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat "
-                                      f"gradient per step" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat gradient per step"
+                                       + (" (fb_vec_step_dp: issued from the C side in two pieces, the W_fc1 / head part overlapped with the conv backward)"
+                                          if native is not None else " (torch.distributed)")) if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    if native is not None:
+        torch.cuda.synchronize()
+        native.close()
     if world > 1:
         dist.destroy_process_group()
 

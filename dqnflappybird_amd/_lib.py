@@ -77,6 +77,13 @@ SIGNATURES = {
     "fb_train_steps": [_vp, _vp, _i, _i, _i] + [_vp] * 7 + [_d, _vp],
     "fb_qnet_sync_target": [_vp, _vp],
     "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
+    "fb_dist_unique_id": [C.c_char_p, _vp],
+    "fb_dist_create": [C.c_char_p, _i, _i, _vp],
+    "fb_dist_destroy": [_vp],
+    "fb_dist_set_overlap": [_vp, _i],
+    "fb_vec_step_dp": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _i, _d, _i, _vp],
+    "fb_dist_reduce_apply": [_vp, _vp, _vp, _i, _vp],
+    "fb_dist_grad_event": [_vp],
     "fb_qnet_set_grad_event": [_vp, _vp],
     "fb_qnet_grad_split": [_vp],
     "fb_train_from_replay": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp],
@@ -113,7 +120,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError = stale library: rebuild it
             fn.argtypes = args
-            fn.restype = C.c_char_p if name in ("fb_last_error", "fb_qnet_kernel_name") else C.c_int64 if name == "fb_qnet_grad_split" else C.c_int
+            fn.restype = C.c_char_p if name in ("fb_last_error", "fb_qnet_kernel_name") else C.c_int64 if name == "fb_qnet_grad_split" else C.c_void_p if name in ("fb_dist_create", "fb_dist_grad_event") else None if name == "fb_dist_destroy" else C.c_int
         _lib = L
     return _lib
 

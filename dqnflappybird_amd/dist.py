@@ -109,3 +109,39 @@ class OverlappedAllReduce:
             L.lib().fb_qnet_set_grad_event(self.net.h, None)
             self.on = False
 
+
+class NativeDP:
+    """The library's own RCCL communicator (csrc/fb_dist.hip): the data-parallel step's all-reduce issued from the C side, straight onto
+    the step's HIP stream, no detour through torch.distributed's RCCL stream (two cross-stream hops per collective); optionally in two
+    pieces with the W_fc1 / head part of the gradient on a side stream behind the fc1 backward launch.  torch.distributed only carries the 128-byte unique id
+    from rank 0 to the others (or nothing at world size 1).  handle: fb_dist_t for vec.VecStep(dist=...)."""
+
+    def __init__(self, rank=None, world=None, overlap=None):
+        """overlap: False = one all-reduce of the whole gradient on the step's stream (default), True = in two pieces with the large one
+        on a side stream behind the fc1 backward launch (default from FB_DP_OVERLAP=1).  See csrc/fb_dist.hip for when which wins."""
+        from . import _lib as L
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        lib = L.lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = path.encode() if os.path.exists(path) else None
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            L.check(lib.fb_dist_unique_id(path, uid.data_ptr()), "fb_dist_unique_id")
+        if self.world > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            t = uid.cuda() if on_gpu else uid
+            dist.broadcast(t, src=0)
+            uid = t.cpu()
+        self.handle = lib.fb_dist_create(path, self.rank, self.world, uid.data_ptr())
+        if not self.handle:
+            raise L.FbError("fb_dist_create: " + lib.fb_last_error().decode("utf-8", "replace"))
+        self.overlap = bool(overlap) if overlap is not None else os.environ.get("FB_DP_OVERLAP", "0") == "1"
+        L.check(lib.fb_dist_set_overlap(self.handle, int(self.overlap)), "fb_dist_set_overlap")
+
+    def close(self):
+        if self.handle:
+            from . import _lib as L
+            L.lib().fb_dist_destroy(self.handle)
+            self.handle = None
+

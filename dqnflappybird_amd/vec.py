@@ -414,9 +414,15 @@ class VecStep:
     The same C-ABI calls in the same order as the separate VecGameState / VecReplay / QNet methods (identical
     results); the pointers are bound once, so the interpreter spends one ctypes call per step instead of five."""
 
-    def __init__(self, env, replay, net, batch=32, algo="dqn", gamma=0.99, flat_grad=None):
+    def __init__(self, env, replay, net, batch=32, algo="dqn", gamma=0.99, flat_grad=None, dist=None, mean_loss=False):
+        """flat_grad: export the gradient instead of applying Adam (data parallel; the caller all-reduces and calls net.apply_adam).
+        dist: a dist.NativeDP -- then the call is fb_vec_step_dp: the step, the all-reduce of flat_grad through the library's own
+        RCCL communicator (overlapped with the conv backward) and Adam, all in the one host call; mean_loss divides by the world size."""
         if replay.prioritized or algo == "per":
             raise ValueError("VecStep is for uniform replay (PER needs the importance weights: use the separate calls)")
+        if dist is not None and flat_grad is None:
+            raise ValueError("VecStep(dist=...) needs the flat_grad buffer the gradient is reduced in")
+        self.dist, self.mean_loss = dist, int(bool(mean_loss))
         if getattr(env, "nib", None) is None:
             raise ValueError("call env.track_state() first: the acting path reads the env kernel's nibble states")
         _dev_check(flat_grad)
@@ -437,6 +443,11 @@ class VecStep:
 
     def __call__(self, epsilon, seed=0, step=0, train=True):
         """-> actions uint8[N] (device); rewards / terminals / scores are the env's tensors, loss is self.loss."""
+        if self.dist is not None:
+            L.check(L.lib().fb_vec_step_dp(self.dist.handle, self.env.h, self.replay.h, self.net.h, C.byref(self.buf), self.env.n, self.algo,
+                                           self.batch, float(epsilon), int(seed), int(step), int(bool(train)), self.gamma, self.mean_loss,
+                                           L.current_stream()), "fb_vec_step_dp")
+            return self.actions
         L.check(L.lib().fb_vec_step(self.env.h, self.replay.h, self.net.h, C.byref(self.buf), self.env.n, self.algo, self.batch,
                                     float(epsilon), int(seed), int(step), int(bool(train)), self.gamma, L.current_stream()),
                 "fb_vec_step")

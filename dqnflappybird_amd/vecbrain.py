@@ -31,9 +31,18 @@ class HipVecBackend:
         from .vec import QNet
         return QNet(actions, fc_width, arch, max_batch=max_batch)
 
-    def step(self, env, replay, net, batch, algo, gamma, flat_grad):
+    def step(self, env, replay, net, batch, algo, gamma, flat_grad, dist=None, mean_loss=False):
         from .vec import VecStep
-        return VecStep(env, replay, net, batch, algo, gamma, flat_grad=flat_grad)
+        return VecStep(env, replay, net, batch, algo, gamma, flat_grad=flat_grad, dist=dist, mean_loss=mean_loss)
+
+    def native(self, rank, world):
+        """the library's own RCCL communicator (dist.NativeDP): with it the whole data-parallel step -- all-reduce and Adam included --
+        is the one host call fb_vec_step_dp.  FB_DP_NATIVE=0 keeps torch.distributed's all-reduce between the step and Adam."""
+        import os
+        import torch.distributed as tdist
+        if os.environ.get("FB_DP_NATIVE", "1") == "0" or not tdist.is_initialized() or tdist.get_backend() != "nccl":
+            return None
+        return fdist.NativeDP(rank, world)
 
     def zeros(self, n):
         import torch
@@ -86,7 +95,15 @@ class VecBrain:
         self.dtype = "f32"
         # uniform replay: the whole step is one host call (fb_vec_step), with the head, random.sample and the Memory append
         # riding in the env launch; PER keeps the separate calls (its sample returns the importance weights)
-        self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad) if algo != "per" else None
+        self.native = None
+        if self.grad is not None and algo != "per" and hasattr(be, "native"):
+            self.native = be.native(rank, world)
+        if algo == "per":
+            self.one_step = None
+        elif self.native is not None:
+            self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad, dist=self.native, mean_loss=MEAN_LOSS[algo])
+        else:
+            self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad)
 
     def train_step(self, idx=None):
         if self.algo in ("nature", "double") and self.timeStep % self.replace_target_iter == 0:
@@ -113,7 +130,7 @@ class VecBrain:
             if self.epsilon > self.final_epsilon and self.onlineTimeStep > self.observe:
                 self.epsilon -= (self.initial_epsilon - self.final_epsilon) / self.explore
             if training:
-                if self.grad is not None:
+                if self.grad is not None and self.native is None:      # (fb_vec_step_dp has reduced and applied already)
                     self.reduce()
                     self.net.apply_adam(self.grad)
                 self.last_loss = self.one_step.loss

@@ -307,6 +307,30 @@ int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch,
 int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int reps, int algo, int batch, const int64_t *idx, uint8_t *a,
                            float *r, uint8_t *t, float *loss, void *stream);
 
+/* ------------------------------------------------------------------ data parallel: one process per GPU, RCCL over xGMI
+ * The only exchange between ranks is the all-reduce of the flat gradient between the backward pass and Adam (envs and replay shards are
+ * rank-local).  fb_vec_step_dp = fb_vec_step(flat_grad) + that all-reduce + fb_qnet_apply_adam in one call, with RCCL called directly
+ * on the step's own stream (no detour through another library's stream).  Optionally (fb_dist_set_overlap) in two pieces: the W_fc1 /
+ * head part of the gradient (91 % of the bytes, final behind the fc1 backward launch) on a side stream while the conv backward still
+ * runs, the conv part on the step's stream, then a join and Adam -- the same sums as one all-reduce of the whole vector.  mean_loss != 0 divides by the world size afterwards (the mean losses of
+ * BrainDQNNature.py:119 / BrainPrioritizedReplyDQN.py:251; BrainDQN's sum loss, BrainDQN.py:162, is a plain sum).
+ * Set-up: rank 0 calls fb_dist_unique_id, hands the 128 bytes to every rank by whatever channel the launcher has (the Python side
+ * broadcasts them, dqnflappybird_amd/dist.py), every rank calls fb_dist_create (collective: ncclCommInitRank) with its HIP device current.
+ * librccl_path: the librccl.so the process already holds (a Python host's framework usually bundles one), or NULL for the default search. */
+typedef struct fb_dist *fb_dist_t;
+int fb_dist_unique_id(const char *librccl_path, uint8_t *id128 /*[host] out*/);
+fb_dist_t fb_dist_create(const char *librccl_path, int rank, int world, const uint8_t *id128 /*[host]*/);
+void fb_dist_destroy(fb_dist_t d);
+/* 0 (default): one all-reduce of the whole gradient on the step's stream; 1: the two-piece schedule described above.  Every cross-stream
+ * dependency costs 5-8 us on this hardware, so the two-piece schedule only pays when the 3.3 MB all-reduce takes longer than ~20 us. */
+int fb_dist_set_overlap(fb_dist_t d, int overlap);
+int fb_vec_step_dp(fb_dist_t d, fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
+                   int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, int mean_loss, void *stream);
+/* The reduction + Adam alone, for a gradient some other call exported (fb_qnet_train_step, fb_train_from_replay) after
+ * fb_qnet_set_grad_event(net, fb_dist_grad_event(d)). */
+int fb_dist_reduce_apply(fb_dist_t d, fb_qnet_t net, float *flat_grad /*[dev]*/, int mean_loss, void *stream);
+void *fb_dist_grad_event(fb_dist_t d);
+
 /* n_steps x (fb_replay_sample -> fb_replay_gather -> fb_qnet_train_step) on a uniform memory in ONE call, same results: only
  * the first draw and the first gather are launches of their own, the draw of step i + 1 rides in step i's conv3 backward
  * launch and its gather in step i's Adam launch (CPython generator; other generators keep their launches).  idx: i64[2 * batch] [dev], two buffers used alternately (step i: idx + (i & 1) * batch);

@@ -426,6 +426,49 @@ def test_overlapped_all_reduce_equals_the_plain_data_parallel_step(torch_cuda):
             tdist.destroy_process_group()
 
 
+@pytest.mark.parametrize("N,algo,overlap", [(512, "dqn", True), (256, "nature", True), (256, "dqn", False)])
+def test_native_dp_step_equals_the_plain_data_parallel_step(torch_cuda, N, algo, overlap):
+    """fb_vec_step_dp (the step, the all-reduce through the library's OWN RCCL communicator -- in line, or in two pieces: tail on a side
+    stream behind the gradient-ready event, front on the step's stream -- and Adam, one host call) == fb_vec_step(flat_grad) + fb_qnet_apply_adam at world
+    size 1, bit for bit: actions, indices and loss step by step, parameters / Adam slots / env states at the end.  (One rank: the
+    collective is RCCL's one-rank copy; what this pins is the choreography -- events, stream order, nothing read before it is final.)"""
+    torch = torch_cuda
+    from dqnflappybird_amd.dist import NativeDP
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+    B, steps = 32, 30
+    nd = NativeDP(rank=0, world=1, overlap=overlap)
+    try:
+        def make(native):
+            env, rep, net = VecGameState(N, seed=5), VecReplay(20000, N), QNet(max_batch=N)
+            rep.seed(9, "cpython"); net.init_params(3, which=0); net.init_params(4, which=1)
+            env.track_state(); env.observe(); rep.reset(env.frame_bits)
+            grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda")
+            return env, rep, net, grad, VecStep(env, rep, net, B, algo, flat_grad=grad, dist=nd if native else None, mean_loss=algo != "dqn")
+
+        e1, r1, n1, g1, plain = make(False)
+        e2, r2, n2, g2, native = make(True)
+        for step in range(steps):
+            train = step >= 8
+            if train and algo == "nature" and step % 5 == 0:
+                n1.sync_target(); n2.sync_target()
+            a1 = plain(0.05, seed=1, step=step, train=train)
+            if train:
+                n1.apply_adam(g1)
+            a2 = native(0.05, seed=1, step=step, train=train)
+            assert torch.equal(a1, a2), step
+            if train:
+                assert torch.equal(plain.idx, native.idx) and torch.equal(plain.loss, native.loss), step
+                assert torch.equal(g1, g2), step
+        assert (e1.get_state() == e2.get_state()).all()
+        assert torch.equal(n1.store_params(), n2.store_params())
+        (m1, v1, p1), (m2, v2, p2) = n1.adam_state(), n2.adam_state()
+        assert torch.equal(m1, m2) and torch.equal(v1, v2) and np.array_equal(p1, p2)
+        assert p1[0] < 0.9 ** (steps - 9)
+    finally:
+        torch.cuda.synchronize()
+        nd.close()
+
+
 def test_graph_replayed_train_steps_refresh_the_acting_weights(torch_cuda):
     """A train step replayed from a captured hipGraph changes the parameters without the host handle noticing: the acting
     forward on >= 256 states (bf16 hi/mid/lo split of the weights) must still re-split them.  Staleness is decided on the

@@ -2,6 +2,8 @@
     fused          fb_vec_step()                                   Adam inside the train step
     dp             fb_vec_step(flat_grad = g) -> all_reduce(g) -> fb_qnet_apply_adam(g)      (what every rank runs when N > 1)
     dp_no_rccl     the same without the collective call            (what the gradient export + the stand-alone Adam cost by themselves)
+    dp_native      fb_vec_step_dp: the all-reduce issued from the C side on the library's own RCCL communicator, on the step's stream
+    dp_native_ov   the same in two pieces, the W_fc1 / head part on a side stream behind the fc1 backward launch (fb_dist_set_overlap)
     dp_overlap     dist.OverlappedAllReduce: the W_fc1 / head part of the gradient reduced on a side stream behind the fc1 backward launch
 with a one-rank RCCL process group, so the all-reduce is a real RCCL call on the step's stream.  python tools/time_dp_step.py [steps]"""
 import os, sys, time
@@ -15,16 +17,26 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 
 
-def build(with_grad):
+NATIVE = None
+
+
+def build(with_grad, native=False):
+    global NATIVE
     env, rep, net = VecGameState(1024, seed=0), VecReplay(1_000_000, 1024), QNet(max_batch=1024)
     rep.seed(0, "cpython"); net.init_params(0)
     env.track_state(); env.observe(); rep.reset(env.frame_bits)
     g = torch.zeros(net.n_params, device="cuda") if with_grad else None
-    return env, rep, net, g, VecStep(env, rep, net, 32, "dqn", flat_grad=g)
+    if native and NATIVE is None:
+        from dqnflappybird_amd.dist import NativeDP
+        NATIVE = NativeDP()
+    if native:
+        from dqnflappybird_amd import _lib as L
+        L.check(L.lib().fb_dist_set_overlap(NATIVE.handle, int(native == "overlap")), "fb_dist_set_overlap")
+    return env, rep, net, g, VecStep(env, rep, net, 32, "dqn", flat_grad=g, dist=NATIVE if native else None)
 
 
 def run(name, with_grad, rccl):
-    env, rep, net, g, one = build(with_grad)
+    env, rep, net, g, one = build(with_grad, native={"native": "inline", "native_overlap": "overlap"}.get(rccl, False))
     red = None
     if rccl == "overlap":
         from dqnflappybird_amd.dist import OverlappedAllReduce
@@ -32,7 +44,7 @@ def run(name, with_grad, rccl):
 
     def step(i):
         one(0.03, seed=0, step=i)
-        if with_grad:
+        if with_grad and rccl not in ("native", "native_overlap"):
             if red is not None:
                 red()
             elif rccl:
@@ -54,4 +66,6 @@ run("fused", False, False)
 run("dp_no_rccl", True, False)
 run("dp", True, True)
 run("dp_overlap", True, "overlap")
+run("dp_native", True, "native")
+run("dp_native_ov", True, "native_overlap")
 dist.destroy_process_group()
