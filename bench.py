@@ -85,7 +85,9 @@ def main():
     replay.seed(seed + rank, "cpython")                     # bit-exact random.sample stream
     net = QNet(2, 512, "plain", max_batch=N_ENVS)
     net.init_params(seed=seed)                              # identical replicas on every rank
-    grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda") if world > 1 else None
+    # rehearsal switch for a one-GPU box: run the N > 1 code path (gradient export, fb_vec_step_dp, the library's RCCL communicator) at world size 1
+    force_dp = os.environ.get("FB_BENCH_FORCE_DP") == "1"
+    grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda") if world > 1 or force_dp else None
     nib = env.track_state()                                 # agents' 4-frame stacks, kept by the env kernel
     env.observe()
     replay.reset(env.frame_bits)
@@ -118,7 +120,7 @@ def main():
     # and fb_qnet_apply_adam (FB_DP_OVERLAP=1: in two pieces, dist.OverlappedAllReduce).
     from dqnflappybird_amd.dist import NativeDP, OverlappedAllReduce
     native = None
-    if world > 1 and backend == "nccl" and os.environ.get("FB_DP_NATIVE", "1") != "0":
+    if (world > 1 or force_dp) and backend == "nccl" and os.environ.get("FB_DP_NATIVE", "1") != "0":
         native = NativeDP(rank, world)
     one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad, dist=native)
     want_overlap = os.environ.get("FB_DP_OVERLAP", "0") == "1"

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, train_from_replay
 n, B = 1024, 32
 env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n), QNet(max_batch=n)
 net.init_params(0)
@@ -19,6 +19,7 @@ for t in range(5):
     idx, _ = replay.sample(B)
     s, aa, r, s2, tt = replay.gather(idx)
     net.train_step("dqn", s, aa, r, s2, tt, want_aux=False)
+    train_from_replay(replay, net, "dqn", idx)        # the ring-fed step the full loop runs (conv23_t_kernel<3, true>, conv_dw21_kernel<2, true>)
 big = torch.randint(0, 40000, (4096,), dtype=torch.int64, device="cuda")
 mid = torch.randint(0, 40000, (256,), dtype=torch.int64, device="cuda")
 for _ in range(3):

@@ -35,10 +35,14 @@ t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, two sepa
               "FETCH_SIZE halves wide coalesced reads on gfx950 (MI355X_MICROARCH.md), hence the factor 2; upper bound for narrow loads.",
      "conv1_sp_kernel<nib>[act n=1024]": pick("conv1_sp_kernel<true>"), "conv23_sp_kernel[act n=1024]": pick("conv23_sp_kernel<3>"),
      "fc1_sp_kernel[act n=1024]": pick("fc1_sp_kernel<3>"), "head_kernel[act n=1024]": pick("head_kernel"),
-     "env_kernel<true>[n=1024]": pick("env_kernel<true>"), "conv1_pool_kernel[train 2B=64]": pick("conv1_pool_kernel<false>"),
-     "conv23_t_kernel[train 2B=64]": pick("conv23_t_kernel<3>"), "fc1_fk_kernel[train 2B=64]": pick("fc1_fk_kernel"),
+     "env_kernel<true>[n=1024]": pick("env_kernel<true>"),
+     "conv1_pool_kernel[train 2B=64, gathered minibatch]": pick("conv1_pool_kernel<false>"),
+     "conv23_t_kernel[train 2B=64, gathered minibatch]": pick("conv23_t_kernel<3, false>"),
+     "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]": pick("conv23_t_kernel<3, true>"),
+     "fc1_fk_kernel[train 2B=64]": pick("fc1_fk_kernel"),
      "fc1_bwd2_kernel": pick("fc1_bwd2_kernel"), "conv_bx_kernel[+ conv3 dW + Adam of W_fc1]": pick("conv_bx_kernel<3>"),
-     "conv_dw21_kernel": pick("conv_dw21_kernel"), "adam_kernel[all but W_fc1]": pick("adam_kernel"),
+     "conv_dw21_kernel[gathered minibatch]": pick("conv_dw21_kernel<2, false>"), "conv_dw21_kernel<ring>": pick("conv_dw21_kernel<2, true>"),
+     "adam_kernel[all but W_fc1]": pick("adam_kernel"),
      "gather_kernel<false>[B=32]": pick("gather_kernel<false>", lambda g: g < 100000),
      "gather_kernel<false>[B=256]": pick("gather_kernel<false>", lambda g: 100000 < g < 1000000),
      "gather_kernel<false>[B=4096]": pick("gather_kernel<false>", lambda g: g > 1000000)}
