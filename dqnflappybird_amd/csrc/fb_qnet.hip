@@ -434,7 +434,10 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
             }
         }
     };
-    int tile = bid * C1_WAVES + wave;
+    // tile -> wave, wave-major: tile = wave * nblk + bid (+ k * stride).  12 800 tiles over 3 072 waves leave 512 waves a fifth tile; in
+    // workgroup-major order those were all 12 waves of 43 workgroups (15 tiles on each of their SIMDs against 12 elsewhere: the launch
+    // lasted as long as those CUs), now they are waves 0 and 1 of every workgroup (13 tiles on two SIMDs of every CU).
+    int tile = wave * nblk + bid;
     if (tile >= ntiles) return;
     Raw cur[16], nxt[16];
     fetch(tile, cur);
