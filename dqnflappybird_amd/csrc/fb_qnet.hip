@@ -749,8 +749,11 @@ struct C23T {
 // pooled pixels over 8 waves, the operand a 256-entry table lookup.  The pooled output goes into conv2's LDS planes directly (and, for
 // the online pass over s, as fp32 + pool positions to global for the backward kernels).  What this replaces: the gather launch with its
 // 51 KB per transition of u8 expansion, and the conv1 launch.
+#ifndef C23T_EXIT
+#define C23T_EXIT 0
+#endif
 template <int NS, bool RING>
-__global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void conv23_t_kernel(C23T a) {      // <= 128 registers: two workgroups per CU
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
     constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RED = ZOFF + 16;
     __shared__ uint4 smem[RED + 2048];
@@ -793,6 +796,11 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         }
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
     } else {
+        // conv1's weight planes (32 KB) go into LDS once, into the reduction area conv2 / conv3 only need later: read from L2 fragment by
+        // fragment inside the tile loop they cost a dependent round trip per pair of taps (4.8 us for the 13 tiles; named registers, see
+        // conv1_sp_kernel)
+        const uint4 *w1g = reinterpret_cast<const uint4 *>(s.w1s);
+        const uint4 wc0 = w1g[tid], wc1 = w1g[tid + 512], wc2 = w1g[tid + 1024], wc3 = w1g[tid + 1536];
         // ---- where the state lives: frames tt - 3 + fshift .. of env e (four threads, one frame offset each)
         if (tid < 4) {
             long long tt; int e;
@@ -810,6 +818,7 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         if (tid < 256) lut[tid] = nib_lut_entry(tid);
         if (tid >= 256 && tid - 256 < FB_NIB_STRIDE / 16) reinterpret_cast<uint4 *>(nibw)[tid - 256] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
+        smem[RED + tid] = wc0; smem[RED + tid + 512] = wc1; smem[RED + tid + 1024] = wc2; smem[RED + tid + 1536] = wc3;
         __syncthreads();
         // ---- nibble image: group gi = 8 pixels of one row = one byte of each frame -> four nibble bytes (pixel pairs), one 4-byte store
         const uint8_t *fb = reinterpret_cast<const uint8_t *>(a.ring.c.bits);
@@ -834,27 +843,30 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
             if (gi < 800) nibw[((y + 2) * FB_NIB_PITCH + 4 + 4 * g) >> 2] = o;
         }
         __syncthreads();
+        if (C23T_EXIT == 1) { if (nibw[tid] == 0x12345u) a.h2[0] = 1.f; return; }
         // ---- conv1 + bias + relu + 2x2 max pool (conv1_pool_kernel's tile loop on the LDS image): tiles wave, wave + 8 of 13
         const uint8_t *nib = reinterpret_cast<const uint8_t *>(nibw);
-        const uint4 *WB = reinterpret_cast<const uint4 *>(s.w1s) + hl * 32 + j;      // [part][ky][kq][h][co] x 16 B
+        const uint4 *WB = smem + RED + lane;                                          // [part][ky][kq][h][co] x 16 B
         const float bias = s.params[OFF_B1 + j];
         for (int tile = wave; tile < 13; tile += 8) {
             const int P = tile * 8 + (j >> 2), pos = j & 3;
             const int py = P / 10, px = P - py * 10, oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
             f32x16 acc = {0}, acl = {0};
-#pragma unroll 2
-            for (int ky = 0; ky < 8; ky++) {
-                const int iy = oy * 4 + ky - 2;
-                const bool rowok = P < 100 && iy >= 0 && iy < 80;
-                const uint8_t *rowp = nib + ((rowok ? iy : 0) + 2) * FB_NIB_PITCH + 4;
+            // the image carries conv1's SAME padding: every tap is base + ky * pitch + 2 * kq -- all 16 byte reads go out first, then the
+            // 16 table reads, then the MFMAs (two LDS latencies per tile instead of two per pair of taps)
+            const uint8_t *base = nib + (4 * (P < 100 ? oy : 0)) * FB_NIB_PITCH + 3 + 2 * (P < 100 ? ox : 0) + hl;
+            unsigned raw[16];
 #pragma unroll
-                for (int kq2 = 0; kq2 < 2; kq2++) {
-                    const int ix = ox * 4 - 2 + 4 * kq2 + 2 * hl;        // even: the pixel pair is inside or outside together
-                    const bool ok = rowok && ix >= 0 && ix < 80;
-                    const unsigned idx = rowp[(ok ? ix : 0) >> 1];
-                    const uint4 A = lut[ok ? idx : 0u];                  // entry 0 = all zero = the SAME padding
-                    acc = mfma_h(A, WB[((0 * 8 + ky) * 2 + kq2) * 64], acc);
-                    acl = mfma_h(A, WB[((1 * 8 + ky) * 2 + kq2) * 64], acl);
+            for (int c = 0; c < 16; c++) raw[c] = base[(c >> 1) * FB_NIB_PITCH + 2 * (c & 1)];
+#pragma unroll
+            for (int h8 = 0; h8 < 2; h8++) {                             // (two halves: 16 operands at once cost 132 registers, one too many
+                uint4 A[8];                                              //  for two workgroups per CU at 256 samples)
+#pragma unroll
+                for (int c = 0; c < 8; c++) A[c] = lut[P < 100 ? raw[8 * h8 + c] : 0u];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    acc = mfma_h(A[c], WB[(0 * 16 + 8 * h8 + c) * 64], acc);
+                    acl = mfma_h(A[c], WB[(1 * 16 + 8 * h8 + c) * 64], acl);
                 }
             }
 #pragma unroll
@@ -881,6 +893,7 @@ __global__ __launch_bounds__(512) void conv23_t_kernel(C23T a) {
         }
     }
     __syncthreads();
+    if (RING && C23T_EXIT == 2) { if (smem[tid].x == 0x12345u) a.h2[0] = 1.f; return; }
     const int oy = j / 5, ox = j - oy * 5;
     const bool rowok = j < 25;
     f32x16 acc = {0}, acl = {0};
