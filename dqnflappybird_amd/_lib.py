@@ -28,6 +28,7 @@ SIGNATURES = {
     "fb_last_error": [],
     "fb_version": [],
     "fb_device_count": [],
+    "fb_debug_abort_backtrace": [],
     "fb_env_create": [_i, _u64, C.c_uint32, _vp, _sz, _vp],
     "fb_env_destroy": [_vp],
     "fb_env_reset": [_vp, _vp],

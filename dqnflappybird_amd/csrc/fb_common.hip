@@ -1,5 +1,8 @@
 // fb_common.hip -- error channel, version, host-side MT19937 seeding.
+#include <execinfo.h>
+#include <signal.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include "fb_common.h"
 
 thread_local char fb_err_buf[512] = "";
@@ -13,6 +16,30 @@ int fb_set_error(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *fb_last_error(void) { return fb_err_buf; }
+
+// Diagnostics: a process that dies in abort() (the HIP / ROCr runtimes do that on fatal errors, sometimes without a message) leaves its
+// native call stack on stderr first.  Async-signal-safe calls only; chains to whatever handler was installed before (Python's
+// faulthandler prints the interpreter's stack after this one).
+static struct sigaction fb_prev_abrt;
+static void fb_abort_backtrace(int sig, siginfo_t *info, void *ctx) {
+    static const char msg[] = "\n[libfbdqn] SIGABRT: native stack of the aborting thread\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) {}
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    if (fb_prev_abrt.sa_flags & SA_SIGINFO) { if (fb_prev_abrt.sa_sigaction) fb_prev_abrt.sa_sigaction(sig, info, ctx); }
+    else if (fb_prev_abrt.sa_handler != SIG_DFL && fb_prev_abrt.sa_handler != SIG_IGN) fb_prev_abrt.sa_handler(sig);
+}
+extern "C" int fb_debug_abort_backtrace(void) {
+    void *warm[4];
+    (void)backtrace(warm, 4);                        // (loads libgcc now: the first call allocates, which a signal handler must not)
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = fb_abort_backtrace;
+    sa.sa_flags = SA_SIGINFO | SA_RESETHAND;
+    sigemptyset(&sa.sa_mask);
+    return sigaction(SIGABRT, &sa, &fb_prev_abrt) == 0 ? FB_OK : fb_set_error(FB_ERR_STATE, "sigaction(SIGABRT) failed");
+}
 extern "C" int fb_version(void) { return 100; }
 
 extern "C" int fb_device_count(void) {

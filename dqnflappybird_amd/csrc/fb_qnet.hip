@@ -2234,6 +2234,145 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
     conv1_dw2_body<NSP, RING>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool, ring);
 }
 
+// ---- conv3 / conv2 weight gradients of a LARGE batch (B a multiple of 16): one workgroup per group of 16 samples and 32 x 32 tile of
+// (input channel, output channel) [conv2: and per parity class of input pixels], on the fp16 matrix instruction with the SAMPLES as the
+// reduction dimension of one MFMA: dW[tap][ci][co] = sum over pixels of ( sum over the 16 samples of x[b][pixel + tap][ci] * dY[b][pixel][co] ),
+// so with both operands parked in LDS as planes [pixel][channel][16 samples] every fragment is ONE 16-byte read at a computed address
+// -- no im2col gather -- and a (tap, pixel) pair is one MFMA step (three products; NS = 1: one bf16 product).  Each workgroup reads its
+// 16 samples' x and dY once (13 MB from L2 per layer at B = 256; the tiled fp32-MFMA kernels re-read them per tile: ~60 MB per layer,
+// 950 + 850 workgroups that each ran one 16-MFMA chunk per wave) and walks all its taps: conv3 9 taps over 8 waves (wave 0 takes the
+// two corner taps 0 and 8), conv2 the 4 taps that meet its parity class x 2 halves of the pixels.  One slab per sample group.
+template <int NS> struct DwgLds {
+    static constexpr int NPL = NS == 3 ? 2 : 1, PLH = 25 * 32 * 16;             // halves per plane of one operand
+    static constexpr int U4 = 2 * NPL * PLH / 8 + 64 + 128 + 2048;               // + a zero page (1 KB) + bias partials (512 floats) + the reduction area (8 x 16 x 64 floats)
+};
+
+// LAYER 3: blk = (group, ci tile, co tile); LAYER 2: blk = (group, parity class, co tile)
+template <int NS, int LAYER>
+__device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs,
+                                              size_t slab_stride, uint4 *pool) {
+    constexpr int NPL = DwgLds<NS>::NPL, PLH = DwgLds<NS>::PLH, ZERO = 2 * NPL * PLH;      // (halves)
+    uint16_t *X = reinterpret_cast<uint16_t *>(pool), *DY = X + NPL * PLH;
+    float *part = reinterpret_cast<float *>(pool + 2 * NPL * PLH / 8 + 64);
+    float *red = part + 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
+    const int cot = blk & 1, mid = LAYER == 3 ? (blk >> 1) & 1 : (blk >> 1) & 3, g = LAYER == 3 ? blk >> 2 : blk >> 3;
+    const int py = mid >> 1, px = mid & 1;                                   // (LAYER 2: the parity class)
+    // ---- the group's operands into LDS as planes [pixel][channel][16 samples].  Item = (pixel, channel, PAIR of samples): two scalar
+    // loads (a half wave reads 32 consecutive channels = 128 B), one packed 4-byte write per plane; lanes of a write are 32 B apart
+    // (4-way bank conflicts; float4 loads with 2-byte writes measured 32-way and made this kernel slower than the tiles it replaces).
+    // Wave-item w = (pixel w % 25, pair quartet w / 25); lane (channel r, hl): sample pair w / 25 + 4 hl.
+    float xa[13], xb[13], ya[13], yb[13];
+#pragma unroll
+    for (int q = 0; q < 13; q++) {
+        const int w = wave + 8 * q, wc = w < 100 ? w : 0, pos = wc % 25, bp = wc / 25 + 4 * hl;
+        const size_t s0 = (size_t)g * 16 + 2 * bp;
+        size_t xo;
+        if (LAYER == 3) xo = (s0 * 25 + pos) * 64 + mid * 32 + r;
+        else { const int qy = pos / 5, qx = pos - qy * 5; xo = (s0 * 100 + (py + 2 * qy) * 10 + px + 2 * qx) * 32 + r; }
+        const size_t yo = (s0 * 25 + pos) * 64 + cot * 32 + r;
+        xa[q] = x[xo]; xb[q] = x[xo + (LAYER == 3 ? 1600 : 3200)];
+        ya[q] = dy[yo]; yb[q] = dy[yo + 1600];
+    }
+    if (tid < 64) pool[2 * NPL * PLH / 8 + tid] = make_uint4(0u, 0u, 0u, 0u);
+    float bs = 0.f;
+#pragma unroll
+    for (int q = 0; q < 13; q++) {
+        const int w = wave + 8 * q, pos = w % 25, bp = w / 25 + 4 * hl;
+        if (w < 100) {
+            const int o = (pos * 32 + r) * 16 + 2 * bp;
+            uint32_t h0, l0, h1, l1, m_;
+            if constexpr (NS == 3) { split2x2(xa[q], xb[q], h0, l0); split2x2(ya[q], yb[q], h1, l1); }
+            else { split3x2(xa[q], xb[q], h0, m_, l0); split3x2(ya[q], yb[q], h1, m_, l1); }
+            *reinterpret_cast<uint32_t *>(X + o) = h0; *reinterpret_cast<uint32_t *>(DY + o) = h1;
+            if (NS == 3) { *reinterpret_cast<uint32_t *>(X + PLH + o) = l0; *reinterpret_cast<uint32_t *>(DY + PLH + o) = l1; }
+            bs += ya[q] + yb[q];
+        }
+    }
+    part[tid] = bs;                                                            // (all items of a thread share its channel r: 512 % 64 == 0)
+    __syncthreads();
+    float *o = slabs + (size_t)g * slab_stride;
+    if (mid == 0 && tid < 32) {                                                // bias gradient of the co tile: column sums of dY, fixed order
+        float sum = 0.f;
+        for (int k = 0; k < 16; k++) sum += part[tid + 32 * k];
+        o[(LAYER == 3 ? OFF_B3 : OFF_B2) + cot * 32 + tid] = sum;
+    }
+    // fragment of pixel `pos` (pos < 0: the zero page -- a tap that falls off the image; no branch, so the 25 steps unroll and their LDS
+    // reads run ahead of the MFMAs)
+    auto frag = [&](const uint16_t *base, int p, int pos) {
+        return *reinterpret_cast<const uint4 *>(pos < 0 ? X + ZERO + 8 * hl : base + p * PLH + (pos * 32 + r) * 16 + 8 * hl);
+    };
+    f32x16 acc = {0}, acl = {0};
+    auto step = [&](int xpos, int pix) {
+        if constexpr (NS == 3) {
+            const uint4 ah = frag(X, 0, xpos), al = frag(X, 1, xpos), bh = frag(DY, 0, pix), bl = frag(DY, 1, pix);
+            acl = mfma_h(ah, bl, acl); acl = mfma_h(al, bh, acl); acc = mfma_h(ah, bh, acc);
+        } else acc = mfma_b(frag(X, 0, xpos), frag(DY, 0, pix), acc);
+    };
+    auto fold = [&]() {
+        if constexpr (NS == 3) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+        }
+    };
+    if constexpr (LAYER == 3) {
+        // wave w: tap w over all 25 pixels, plus pixels 3 w .. 3 w + 2 (wave 7: .. 24) of the ninth tap into a second accumulator pair whose
+        // eight partial sums meet through LDS (one wave doing two whole taps made the workgroup wait for it: 50 steps against 25)
+        {
+            const int ky = wave / 3, kx = wave - 3 * ky;
+#pragma unroll
+            for (int pix = 0; pix < 25; pix++) {
+                const int oy = pix / 5, ox = pix - oy * 5, iy = oy + ky - 1, ix = ox + kx - 1;
+                step(iy >= 0 && iy < 5 && ix >= 0 && ix < 5 ? iy * 5 + ix : -1, pix);
+            }
+            fold();
+#pragma unroll
+            for (int q = 0; q < 16; q++) o[OFF_W3 + (size_t)((wave * 64 + mid * 32 + drow(q, lane)) * 64) + cot * 32 + r] = acc[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) { acc[q] = 0.f; acl[q] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                                          // tap 8 = (ky, kx) = (2, 2): input pixel (oy + 1, ox + 1)
+            const int pix = 3 * wave + k, pc = pix < 25 ? pix : 0, oy = pc / 5, ox = pc - oy * 5;
+            const bool mine = k < 3 || wave == 7;
+            step(mine && pix < 25 && oy < 4 && ox < 4 ? (oy + 1) * 5 + ox + 1 : -1, pc);
+        }
+        fold();
+        reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
+            o[OFF_W3 + (size_t)((8 * 64 + mid * 32 + row32) * 64) + cot * 32 + r] = v;
+        });
+    } else {
+        // wave w: tap (a, b2) = w & 3 of the class, pixels [13 * (w >> 2), ..): the two halves meet through LDS
+        const int t4 = wave & 3, a2 = t4 >> 1, b2 = t4 & 1, half = wave >> 2;
+        const int ky = ((py + 1) & 1) + 2 * a2, kx = ((px + 1) & 1) + 2 * b2;
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const int pix = half * 13 + k, pc = pix < 25 ? pix : 0;
+            const int oy = pc / 5, ox = pc - oy * 5, qy = oy + a2 - py, qx = ox + b2 - px;
+            step(pix < 25 && qy >= 0 && qy < 5 && qx >= 0 && qx < 5 ? qy * 5 + qx : -1, pc);
+        }
+        fold();
+        if (half) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) red[(t4 * 16 + q) * 64 + lane] = acc[q];
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                o[OFF_W2 + (size_t)(((ky * 4 + kx) * 32 + drow(q, lane)) * 64) + cot * 32 + r] = acc[q] + red[(t4 * 16 + q) * 64 + lane];
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void conv_dwg_kernel(int n3, const float *__restrict__ h2, const float *__restrict__ dh3, const float *__restrict__ p1,
+                                                       const float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride) {
+    __shared__ uint4 pool[DwgLds<NS>::U4];
+    if ((int)blockIdx.x < n3) conv_dwg_body<NS, 3>(blockIdx.x, h2, dh3, slabs, slab_stride, pool);
+    else conv_dwg_body<NS, 2>(blockIdx.x - n3, p1, dh2, slabs, slab_stride, pool);
+}
+
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
 // walk up to 7 chunks one after the other (94 us at B = 256).  It is cut into up to 4 x 64 sub-slabs instead (one chunk
 // per wave again) and this kernel folds groups of 4 into the 64 slabs the Adam kernel sums, in a fixed order.
@@ -2671,7 +2810,6 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         int z3 = (B * 25 + 255) / 256, z1 = (B * 400 + 255) / 256;
         if (z3 > h->zmax) z3 = h->zmax;
         if (z1 > h->zmax) z1 = h->zmax;
-        const int z2 = z3;
         const size_t ss = CONV_PARAMS;
         const int ndx1 = ((B + 31) / 32) * 50;
         if (fk) { FB_K(K_FC1_BWD) {
@@ -2713,21 +2851,34 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             z1 = fold1 ? (2 * B + fold - 1) / fold : 2 * B;
             const int n_adam5 = (span1 - span0 + 511) / 512;
             const BxArgs bx{h->dh3, h->h2, h->p1, h->dh2, h->dp1, h->wsp[0] + wsp_w3t(FC), h->wsp[0] + wsp_w2t(FC)};
+            // large batches (multiples of 16): conv3's and conv2's weight gradients per group of 16 samples in a launch of their own
+            // (conv_dwg_kernel) instead of as 38 + 34 tiles per slab inside the two launches below; one slab per group
+            const bool dwg = big && B % 16 == 0;
+            const int zt3 = dwg ? 0 : z3, zt2 = zt3;
             FB_K(K_CONV3_BWD) {
-                const dim3 g(B + 38 * z3 + n_adam5 + (srider.k ? 1 : 0));
-                if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_bx_kernel<3>, g, dim3(512), 0, st, bx, B, z3, h->slabs, ss, n_adam5, span, srider, rbt);
-                else hipLaunchKernelGGL(conv_bx_kernel<1>, g, dim3(512), 0, st, bx, B, z3, h->slabs, ss, n_adam5, span, srider, rbt);
+                const dim3 g(B + 38 * zt3 + n_adam5 + (srider.k ? 1 : 0));
+                if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_bx_kernel<3>, g, dim3(512), 0, st, bx, B, zt3, h->slabs, ss, n_adam5, span, srider, rbt);
+                else hipLaunchKernelGGL(conv_bx_kernel<1>, g, dim3(512), 0, st, bx, B, zt3, h->slabs, ss, n_adam5, span, srider, rbt);
+            }
+            if (dwg) {
+                z3 = B / 16;                                 // (conv2's slab count follows: z2 below)
+                FB_K(K_CONV2_BWD) {
+                    const int n3 = z3 * 4, n2 = z3 * 8;
+                    if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_dwg_kernel<3>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss);
+                    else hipLaunchKernelGGL(conv_dwg_kernel<1>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss);
+                }
             }
             FB_K(K_CONV2_BWD) {
                 const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
                 float *s1 = fold1 ? h->slabs1 : h->slabs;
                 const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
-                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
-                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * z2 + 2 * B), dim3(512), 0, st, z2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
+                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * zt2 + 2 * B), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
+                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
             }
         }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
+        const int z2 = z3;
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
         {

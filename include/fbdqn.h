@@ -40,6 +40,9 @@ const char *fb_last_error(void);
 int fb_version(void);
 /* number of visible HIP devices, or a negative error; used by the shim to fail loudly */
 int fb_device_count(void);
+/* Diagnostics: install a SIGABRT handler that writes the aborting thread's native call stack to stderr before the previous handler
+ * runs (the GPU runtimes abort() on fatal errors, not always with a message). */
+int fb_debug_abort_backtrace(void);
 
 /* ------------------------------------------------------------------ environment
  * N independent games stepped per launch, render + 80x80 preprocess fused in.

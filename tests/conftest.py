@@ -26,3 +26,15 @@ def oracle():
     from oracle import oracle as o
     o.lib()
     return o
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_stack_on_abort():
+    """The GPU runtimes abort() on fatal errors, not always with a message: have the library print the native call stack of the aborting
+    thread first (pytest's faulthandler then adds the interpreter's).  Diagnostics only; never fails a run."""
+    try:
+        from dqnflappybird_amd import _lib
+        _lib.lib().fb_debug_abort_backtrace()
+    except Exception:
+        pass
+    yield
