@@ -87,7 +87,7 @@ SIGNATURES = {
     "fb_dist_grad_event": [_vp],
     "fb_qnet_set_grad_event": [_vp, _vp],
     "fb_qnet_grad_split": [_vp],
-    "fb_train_from_replay": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp],
+    "fb_train_from_replay": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp],
     "fb_profile_ring_kernel": [_vp, _vp, _i, _i, _i, _i] + [_vp] * 6,
     "fb_qnet_kernel_name": [_i],
     "fb_vec_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _i, _d, _vp],

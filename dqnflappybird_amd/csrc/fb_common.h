@@ -81,10 +81,10 @@ int fb_replay_gather_rider(fb_replay_t h, int batch, const int64_t *idx, uint8_t
 // the 1-bit frames itself (no gather launch, no u8 expansion) and fills a / r / t (u8 / f32 / u8 [B], [dev]) for the loss.
 struct FbRingSrc { FbGatherCtx c; long long steps; const long long *idx; uint8_t *a; float *r; uint8_t *t; };
 int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a, float *r, uint8_t *t, FbRingSrc *out);
-// fb_qnet_train_step on such a minibatch (uniform algorithms).  The split conv planes of both nets must be current: true
+// fb_qnet_train_step on such a minibatch (isw / abs_err: the prioritized step's importance weights in, |TD errors| out; else NULL).  The split conv planes of both nets must be current: true
 // after an acting forward of >= 256 states in the same stream order (fb_vec_step), which is the only caller.
-int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, double gamma, float *loss, float *flat_grad,
-                            void *stream);
+int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, const float *isw, double gamma, float *loss,
+                            float *abs_err, float *flat_grad, void *stream);
 int fb_qnet_refresh_planes(fb_qnet_t h, void *stream);      // re-split whichever net's planes are stale (decided on the device)
 int fb_qnet_profile_ring(fb_qnet_t h, int kernel, int reps, int algo, int batch, const FbRingSrc *ring, float *loss, void *stream);
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight

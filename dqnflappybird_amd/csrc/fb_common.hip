@@ -150,7 +150,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
         FbRingSrc ring;
         rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
         if (rc != FB_OK) return rc;
-        return fb_qnet_train_step_ring(net, algo, batch, &ring, gamma, b->loss, b->flat_grad, stream);
+        return fb_qnet_train_step_ring(net, algo, batch, &ring, nullptr, gamma, b->loss, nullptr, b->flat_grad, stream);
     }
     rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
     if (rc != FB_OK) return rc;
@@ -158,17 +158,18 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
                               stream);
 }
 
-extern "C" int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, uint8_t *a, float *r,
-                                    uint8_t *t, double gamma, float *loss, float *flat_grad, void *stream) {
+extern "C" int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, const float *isw, uint8_t *a,
+                                    float *r, uint8_t *t, double gamma, float *loss, float *abs_err, float *flat_grad, void *stream) {
     FB_REQUIRE(replay && net && idx && a && r && t && loss, "fb_train_from_replay: NULL argument");
-    FB_REQUIRE(algo == FB_ALGO_DQN || algo == FB_ALGO_NATURE || algo == FB_ALGO_DOUBLE, "fb_train_from_replay: algo must be DQN, NATURE or DOUBLE");
+    FB_REQUIRE(algo >= 0 && algo <= 3, "fb_train_from_replay: unknown algo %d", algo);
+    FB_REQUIRE(algo != FB_ALGO_PER || isw, "fb_train_from_replay: the prioritized step needs the importance weights");
     FB_REQUIRE(batch >= 1 && batch <= 256, "fb_train_from_replay: batch must be in 1..256");
     FbRingSrc ring;
     int rc = fb_replay_ring_src(replay, batch, idx, a, r, t, &ring);
     if (rc != FB_OK) return rc;
     rc = fb_qnet_refresh_planes(net, stream);       // (fb_vec_step needs no such launch: its acting forward has just done it)
     if (rc != FB_OK) return rc;
-    return fb_qnet_train_step_ring(net, algo, batch, &ring, gamma, loss, flat_grad, stream);
+    return fb_qnet_train_step_ring(net, algo, batch, &ring, isw, gamma, loss, abs_err, flat_grad, stream);
 }
 
 extern "C" int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int reps, int algo, int batch, const int64_t *idx,

@@ -3015,18 +3015,33 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
     return FB_OK;
 }
 
-int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, double gamma, float *loss, float *flat_grad, void *stream) {
+int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, const float *isw, double gamma, float *loss, float *abs_err,
+                            float *flat_grad, void *stream) {
     FB_REQUIRE(h && ring && ring->idx && ring->a && ring->r && ring->t, "fb_qnet_train_step_ring: NULL argument");
-    FB_REQUIRE(algo != FB_ALGO_PER, "fb_qnet_train_step_ring: uniform memories only");
     Plan p;
-    int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, nullptr, gamma, loss, nullptr, nullptr, flat_grad, &p, ring);
+    int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, isw, gamma, loss, abs_err, nullptr, flat_grad, &p, ring);
     if (rc != FB_OK) return rc;
     return run_plan(h, p, -1, fb_stream(stream));
 }
 
+// both nets in one launch (blockIdx.y = net; every thread checks its net's versions) + one marking launch
+__global__ void wsplit_both_kernel(const float *__restrict__ p0, const float *__restrict__ p1, uint4 *__restrict__ w0, uint4 *__restrict__ w1, int FC,
+                                   const AdamDev *__restrict__ ad) {
+    const int n = blockIdx.y;
+    if (ad->pver[n] == ad->wver[n]) return;
+    wsplit_item(n ? p1 : p0, n ? w1 : w0, FC, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void mark_split_both_kernel(AdamDev *ad) {
+    const int n = threadIdx.x;
+    if (n < 2) { ad->wver[n] = ad->pver[n]; ad->wverc[n] = ad->pver[n]; }
+}
+
 int fb_qnet_refresh_planes(fb_qnet_t h, void *stream) {
     FB_REQUIRE(h, "fb_qnet_refresh_planes: NULL handle");
-    for (int n = 0; n < 2; n++) resplit_now(h, n, fb_stream(stream));       // (wsplit_kernel returns at once when the versions agree)
+    const int items = wsplit_items(h->FC);
+    hipLaunchKernelGGL(wsplit_both_kernel, dim3((items + 255) / 256, 2), dim3(256), 0, fb_stream(stream), h->params[0], h->params[1], h->wsp[0], h->wsp[1],
+                       h->FC, (const AdamDev *)h->adam);      // (returns at once for a net whose versions agree)
+    hipLaunchKernelGGL(mark_split_both_kernel, dim3(1), dim3(64), 0, fb_stream(stream), h->adam);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

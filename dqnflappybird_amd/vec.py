@@ -368,20 +368,24 @@ class QNet:
         L.check(L.lib().fb_qnet_apply_adam(self.h, L.ptr(flat_grad), L.current_stream()), "fb_qnet_apply_adam")
 
 
-def train_from_replay(replay, net, algo, idx, gamma=0.99, flat_grad=None):
+def train_from_replay(replay, net, algo, idx, gamma=0.99, flat_grad=None, isw=None, want_abs_err=False):
     """replay.gather(idx) + net.train_step(...) without the gathered copies (fb_train_from_replay): the conv trunk reads the sampled
-    transitions' 1-bit frames in the ring directly.  Same results as the two calls (batch < 256; "dqn", "nature", "double").
-    -> (loss f32[1], a u8[B], r f32[B], t u8[B]) on the device."""
-    if replay.prioritized or algo == "per":
-        raise ValueError("train_from_replay is for uniform replay (PER needs the importance weights: use the separate calls)")
-    _dev_check(idx, flat_grad)
+    transitions' 1-bit frames in the ring directly.  Same results as the two calls (batch <= 256).  Prioritized replay: idx are the
+    SumTree leaf indices of replay.sample, isw its importance weights; want_abs_err returns |TD error| for update_priorities.
+    -> (loss f32[1], a u8[B], r f32[B], t u8[B][, abs_err f32[B]]) on the device."""
+    if (replay.prioritized or algo == "per") and isw is None:
+        raise ValueError("the prioritized step needs the importance weights (isw)")
+    _dev_check(idx, flat_grad, isw)
     B, dev = int(idx.numel()), idx.device
     a = torch.empty(B, dtype=torch.uint8, device=dev); r = torch.empty(B, dtype=torch.float32, device=dev)
     t = torch.empty(B, dtype=torch.uint8, device=dev); loss = torch.zeros(1, dtype=torch.float32, device=dev)
-    L.check(L.lib().fb_train_from_replay(replay.h, net.h, ALGOS[algo], B, L.ptr(idx), L.ptr(a), L.ptr(r), L.ptr(t), float(gamma),
-                                         L.ptr(loss), None if flat_grad is None else L.ptr(flat_grad), L.current_stream()),
+    ae = torch.empty(B, dtype=torch.float32, device=dev) if want_abs_err else None
+    if isw is not None and isw.dtype != torch.float32:
+        isw = isw.to(torch.float32)                      # ISWeights is fed to a float32 placeholder
+    L.check(L.lib().fb_train_from_replay(replay.h, net.h, ALGOS[algo], B, L.ptr(idx), L.ptr(isw), L.ptr(a), L.ptr(r), L.ptr(t), float(gamma),
+                                         L.ptr(loss), L.ptr(ae), L.ptr(flat_grad), L.current_stream()),
             "fb_train_from_replay")
-    return loss, a, r, t
+    return (loss, a, r, t, ae) if want_abs_err else (loss, a, r, t)
 
 
 class TrainSteps:

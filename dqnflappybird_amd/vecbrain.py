@@ -48,6 +48,12 @@ class HipVecBackend:
         import torch
         return torch.zeros(n, dtype=torch.float32, device="cuda")
 
+    def train_from_replay(self, replay, net, algo, idx, isw, gamma, flat_grad, want_abs_err):
+        """minibatch assembly + train step from the sampled indices on, without gathered copies -> (loss, abs_err or None)"""
+        from .vec import train_from_replay
+        out = train_from_replay(replay, net, algo, idx, gamma, flat_grad, isw=isw, want_abs_err=want_abs_err)
+        return out[0], (out[4] if want_abs_err else None)
+
     def reducer(self, net, flat_grad, mean_loss):
         """-> callable that all-reduces flat_grad over the ranks: one collective; with FB_DP_OVERLAP=1 two, the large one overlapped
         with the conv backward (dist.OverlappedAllReduce -- off by default, see its docstring)"""
@@ -62,6 +68,7 @@ class VecBrain:
                  observe=1000, explore=1_000_000, initial_epsilon=0.03, final_epsilon=0.0, gamma=0.99,
                  replace_target_iter=500, sampler=None, rank=0, world=1, backend=None):
         be = backend or HipVecBackend()
+        self.be = be
         self.n, self.algo, self.batch, self.gamma = n_envs, algo, batch, gamma
         self.rank, self.world = rank, world
         self.observe, self.explore = observe, explore
@@ -111,9 +118,13 @@ class VecBrain:
         isw = None
         if idx is None:
             idx, isw = self.replay.sample(self.batch)
-        s, a, r, s2, t = self.replay.gather(idx)
-        loss, abs_err, _ = self.net.train_step(self.algo, s, a, r, s2, t, isw=isw, gamma=self.gamma, flat_grad=self.grad,
-                                               want_aux=self.algo == "per")
+        if hasattr(self.be, "train_from_replay") and self.batch <= 256:
+            # the conv trunk reads the sampled transitions' frame bits in the ring: no gather launch, no u8 copies
+            loss, abs_err = self.be.train_from_replay(self.replay, self.net, self.algo, idx, isw, self.gamma, self.grad, self.algo == "per")
+        else:
+            s, a, r, s2, t = self.replay.gather(idx)
+            loss, abs_err, _ = self.net.train_step(self.algo, s, a, r, s2, t, isw=isw, gamma=self.gamma, flat_grad=self.grad,
+                                                   want_aux=self.algo == "per")
         if self.grad is not None:
             self.reduce()
             self.net.apply_adam(self.grad)

@@ -302,10 +302,10 @@ int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_b
 /* fb_replay_gather + fb_qnet_train_step WITHOUT the gathered copies (BrainDQN.py:197-223 from the indices on): the minibatch is
  * described by its indices, the conv trunk reads the replay's 1-bit frames directly (5 x 800 B per transition instead of writing and
  * re-reading 51 KB of u8 expansion) and fills a, r, t (u8 / f32 / u8 [batch], [dev] out).  Bit-identical to the two separate calls.
- * batch <= 256; algo = DQN / NATURE / DOUBLE (a prioritized step needs the importance weights: separate calls); flat_grad as in
- * fb_qnet_train_step. */
-int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, uint8_t *a, float *r, uint8_t *t,
-                         double gamma, float *loss, float *flat_grad, void *stream);
+ * batch <= 256.  isw f32[batch] (the prioritized step's importance weights, idx then are SumTree leaf indices) or NULL; abs_err f32[batch]
+ * out (|TD error|, for fb_replay_update_priorities) or NULL; flat_grad as in fb_qnet_train_step. */
+int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo, int batch, const int64_t *idx, const float *isw, uint8_t *a, float *r,
+                         uint8_t *t, double gamma, float *loss, float *abs_err, float *flat_grad, void *stream);
 /* Measurement aid: kernel `kernel` (ids of fb_qnet_kernel_name) of that step's plan, `reps` times, like fb_qnet_profile_kernel. */
 int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int reps, int algo, int batch, const int64_t *idx, uint8_t *a,
                            float *r, uint8_t *t, float *loss, void *stream);

@@ -371,6 +371,37 @@ def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
 
 
+def test_train_from_replay_prioritized_equals_the_separate_calls(torch_cuda):
+    """The prioritized step through fb_train_from_replay (SumTree leaf indices, importance weights in, |TD errors| out) ==
+    fb_replay_gather + fb_qnet_train_step(isw) + the same priorities update, bit for bit over several sample / train / update rounds."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, train_from_replay
+    N, B = 64, 32
+    env = VecGameState(N, seed=3); env.observe()
+    reps = [VecReplay(4096, N, prioritized=True) for _ in range(2)]
+    for rp in reps:
+        rp.seed(5, "numpy"); rp.reset(env.frame_bits)
+    rng = np.random.default_rng(0)
+    for _ in range(30):
+        acts = torch.from_numpy((rng.random(N) < 0.15).astype(np.uint8)).cuda()
+        env.frame_step(acts, want_u8=False)
+        for rp in reps:
+            rp.push(env.frame_bits, acts, env.reward, env.terminal)
+    n1, n2 = QNet(max_batch=B), QNet(max_batch=B)
+    for n in (n1, n2):
+        n.init_params(7); n.sync_target()
+    for step in range(5):
+        (i1, w1), (i2, w2) = reps[0].sample(B), reps[1].sample(B)
+        assert torch.equal(i1, i2) and torch.equal(w1, w2)
+        s, a, r, s2, t = reps[0].gather(i1)
+        l1, ae1, _ = n1.train_step("per", s, a, r, s2, t, isw=w1, want_aux=True)
+        l2, a2, r2, t2, ae2 = train_from_replay(reps[1], n2, "per", i2, isw=w2, want_abs_err=True)
+        assert torch.equal(a, a2) and torch.equal(r, r2) and torch.equal(t, t2)
+        assert torch.equal(l1, l2) and torch.equal(ae1, ae2), step
+        reps[0].update_priorities(i1, abs_err=ae1); reps[1].update_priorities(i2, abs_err=ae2)
+    assert torch.equal(n1.store_params(), n2.store_params())
+
+
 def test_overlapped_all_reduce_equals_the_plain_data_parallel_step(torch_cuda):
     """dist.OverlappedAllReduce (the gradient's W_fc1 / head part reduced on a side stream that waits for the event fb_vec_step records
     behind its fc1 backward launch, the conv part on the step's stream, then a join) == one all-reduce of the whole vector, through a
