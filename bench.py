@@ -121,7 +121,16 @@ def main():
     from dqnflappybird_amd.dist import NativeDP, OverlappedAllReduce
     native = None
     if (world > 1 or force_dp) and backend == "nccl" and os.environ.get("FB_DP_NATIVE", "1") != "0":
-        native = NativeDP(rank, world)
+        try:
+            native = NativeDP(rank, world)
+        except Exception as e:                               # pragma: no cover  (no RCCL to load, communicator refused, ...)
+            print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        if world > 1:                                        # every rank takes the same path: all of them native, or none
+            ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0 and native is not None:
+                native.close()
+                native = None
     one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad, dist=native)
     want_overlap = os.environ.get("FB_DP_OVERLAP", "0") == "1"
     reduce_grad = OverlappedAllReduce(net, grad, mean_loss=False) if world > 1 and backend == "nccl" and want_overlap and native is None else None
