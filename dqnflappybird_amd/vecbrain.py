@@ -42,7 +42,18 @@ class HipVecBackend:
         import torch.distributed as tdist
         if os.environ.get("FB_DP_NATIVE", "1") == "0" or not tdist.is_initialized() or tdist.get_backend() != "nccl":
             return None
-        return fdist.NativeDP(rank, world)
+        import torch
+        native = None
+        try:
+            native = fdist.NativeDP(rank, world)
+        except Exception:                                    # no RCCL to load, communicator refused, ...: torch's collective instead
+            native = None
+        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device="cuda")
+        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)          # every rank takes the same path
+        if ok.item() == 0 and native is not None:
+            native.close()
+            native = None
+        return native
 
     def zeros(self, n):
         import torch
