@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfbdqn.so")
+LIB_PATH = os.environ.get("FB_LIB") or os.path.join(_HERE, "libfbdqn.so")      # FB_LIB: an ablation / tuning build (tools/)
 ASSET_BLOB = os.path.join(_HERE, "assets", "sprites.bin")
 
 FB_OK = 0
