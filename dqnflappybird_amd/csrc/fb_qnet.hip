@@ -752,8 +752,9 @@ struct C23T {
 #ifndef C23T_EXIT
 #define C23T_EXIT 0
 #endif
-template <int NS, bool RING>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void conv23_t_kernel(C23T a) {      // <= 128 registers: two workgroups per CU
+// W16 (ring-fed, small batches): sixteen waves per workgroup -- conv1's 13 tiles in ONE round instead of two; waves 8 .. 15 leave after it
+template <int NS, bool RING, bool W16 = false>
+__global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(4))) void conv23_t_kernel(C23T a) {      // <= 128 registers: two workgroups per CU
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
     constexpr int IN_P = 400, C2_P = 200, C2O = NPL * IN_P, ZOFF = C2O + NPL * C2_P, RED = ZOFF + 16;
     __shared__ uint4 smem[RED + 2048];
@@ -777,7 +778,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
         for (int p = 0; p < NPL; p++) r.v[p] = w[((size_t)(8 * c + 2 * kq + hl) * 3 + P0 + p) * 64 + ct * 32 + j];
         return r;
     };
-    WF w0 = loadW(0), w1 = loadW(1), w2 = loadW(2);
+    WF w0 = {}, w1 = {}, w2 = {};
+    if (!W16 || wave < 8) { w0 = loadW(0); w1 = loadW(1); w2 = loadW(2); }
     if constexpr (!RING) {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
         float4 t[2];
 #pragma unroll
@@ -800,7 +802,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
         // fragment inside the tile loop they cost a dependent round trip per pair of taps (4.8 us for the 13 tiles; named registers, see
         // conv1_sp_kernel)
         const uint4 *w1g = reinterpret_cast<const uint4 *>(s.w1s);
-        const uint4 wc0 = w1g[tid], wc1 = w1g[tid + 512], wc2 = w1g[tid + 1024], wc3 = w1g[tid + 1536];
+        const int t5 = tid & 511;                                             // (W16: threads 512 .. 1023 repeat the first half's copies)
+        const uint4 wc0 = w1g[t5], wc1 = w1g[t5 + 512], wc2 = w1g[t5 + 1024], wc3 = w1g[t5 + 1536];
         // ---- where the state lives: frames tt - 3 + fshift .. of env e (four threads, one frame offset each)
         if (tid < 4) {
             long long tt; int e;
@@ -818,20 +821,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
         if (tid < 256) lut[tid] = nib_lut_entry(tid);
         if (tid >= 256 && tid - 256 < FB_NIB_STRIDE / 16) reinterpret_cast<uint4 *>(nibw)[tid - 256] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
-        smem[RED + tid] = wc0; smem[RED + tid + 512] = wc1; smem[RED + tid + 1024] = wc2; smem[RED + tid + 1536] = wc3;
+        if (tid < 512) { smem[RED + tid] = wc0; smem[RED + tid + 512] = wc1; smem[RED + tid + 1024] = wc2; smem[RED + tid + 1536] = wc3; }
         __syncthreads();
         // ---- nibble image: group gi = 8 pixels of one row = one byte of each frame -> four nibble bytes (pixel pairs), one 4-byte store
         const uint8_t *fb = reinterpret_cast<const uint8_t *>(a.ring.c.bits);
         uint32_t fbyte[2][4];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int gi = tid + 512 * r, gc = gi < 800 ? gi : 0;
+            const int gi = t5 + 512 * r, gc = gi < 800 ? gi : 0;
 #pragma unroll
             for (int f = 0; f < 4; f++) fbyte[r][f] = fb[fo[f] * 8 + gc];
         }
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int gi = tid + 512 * r, y = gi / 10, g = gi - y * 10;
+            const int gi = t5 + 512 * r, y = gi / 10, g = gi - y * 10;
             uint32_t o = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
                     const uint32_t t2 = (fbyte[r][f] >> (2 * q)) & 3u;           // pixels 2q, 2q + 1 of the group in frame f
                     o |= ((t2 & 1u) | ((t2 & 2u) << 3)) << (8 * q + f);            // bit 4 * px + f of nibble byte q
                 }
-            if (gi < 800) nibw[((y + 2) * FB_NIB_PITCH + 4 + 4 * g) >> 2] = o;
+            if (gi < 800 && tid < 512) nibw[((y + 2) * FB_NIB_PITCH + 4 + 4 * g) >> 2] = o;
         }
         __syncthreads();
         if (C23T_EXIT == 1) { if (nibw[tid] == 0x12345u) a.h2[0] = 1.f; return; }
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
         const uint8_t *nib = reinterpret_cast<const uint8_t *>(nibw);
         const uint4 *WB = smem + RED + lane;                                          // [part][ky][kq][h][co] x 16 B
         const float bias = s.params[OFF_B1 + j];
-        for (int tile = wave; tile < 13; tile += 8) {
+        for (int tile = wave; tile < 13; tile += W16 ? 16 : 8) {
             const int P = tile * 8 + (j >> 2), pos = j & 3;
             const int py = P / 10, px = P - py * 10, oy = 2 * py + (pos >> 1), ox = 2 * px + (pos & 1);
             f32x16 acc = {0}, acl = {0};
@@ -893,6 +896,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void c
         }
     }
     __syncthreads();
+    if (W16 && wave >= 8) return;                    // (their part -- conv1's tiles 8 .. 12 -- is done; s_barrier only counts the waves that are left)
     if (RING && C23T_EXIT == 2) { if (smem[tid].x == 0x12345u) a.h2[0] = 1.f; return; }
     const int oy = j / 5, ox = j - oy * 5;
     const bool rowok = j < 25;
@@ -2725,7 +2729,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     if (trunk) FB_K(K_CONV2) {                       // conv1 + pool + conv2 + conv3 of every state in ONE launch
         if (sp) { c23t.a3s = h->a3s; c23t.pl3 = pl2; }      // >= 256 states per slice: fc1_sp_kernel follows and reads conv3's output as planes
         c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
-        if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        const bool w16 = maxc * p.ns <= 256;          // at most one workgroup per CU anyway: spend the idle SIMD slots on conv1's second round
+        if (nsp == 3 && w16) hipLaunchKernelGGL((conv23_t_kernel<3, true, true>), dim3(maxc, p.ns), dim3(1024), 0, st, c23t);
+        else if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
+        else if (w16) hipLaunchKernelGGL((conv23_t_kernel<1, true, true>), dim3(maxc, p.ns), dim3(1024), 0, st, c23t);
         else hipLaunchKernelGGL((conv23_t_kernel<1, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
     }
     if (sp) {
