@@ -293,8 +293,9 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("algo,B", [("dqn", 32), ("nature", 17), ("double", 64), ("double", 256)])
-def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B):
+@pytest.mark.parametrize("algo,B,dtype", [("dqn", 32, "f32"), ("nature", 17, "f32"), ("double", 64, "f32"), ("double", 256, "f32"),
+                                          ("nature", 32, "bf16"), ("double", 160, "bf16")])
+def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B, dtype):
     """fb_train_from_replay (the conv trunk reads the sampled transitions' 1-bit frames in the ring; no gathered copies) ==
     fb_replay_gather + fb_qnet_train_step, bit for bit below 256 samples: a / r / t, loss, parameters and Adam slots over several steps, on a ring
     that has wrapped, with indices at both ends of the deque, right after a target sync and after a stand-alone Adam (stale planes)."""
@@ -310,7 +311,7 @@ def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B):
         rep.push(env.frame_bits, acts, env.reward, env.terminal)
     n1, n2 = QNet(max_batch=B), QNet(max_batch=B)
     for n in (n1, n2):
-        n.init_params(7); n.sync_target()
+        n.init_params(7); n.sync_target(); n.set_train_dtype(dtype)     # (bf16: the one-plane instantiations of the same kernels)
     size = len(rep)
     # B = 256: the separate calls run the large-batch kernels (another summation order in conv2 / conv3), so equal to rounding only
     same = (lambda x, y: torch.equal(x, y)) if B < 256 else (lambda x, y: torch.allclose(x, y, rtol=2e-4, atol=2e-6))
