@@ -203,7 +203,7 @@ __device__ __forceinline__ uint4 nib_lut_entry(unsigned t) {   // byte t = 2 pix
 }
 
 // conv1 8x8x4->32 stride 4 SAME(2,2) + bias + relu + max_pool 2x2; one wave per tile of 8 pooled pixels x 4
-// window positions (the pool is a max over 4 accumulator registers of one lane), 48 bf16 MFMAs per tile.
+// window positions (the pool is a max over 4 accumulator registers of one lane), 32 fp16 MFMAs per tile.
 // NIB = false: states are u8[n][80][80][4] (the reference's layout).  NIB = true (acting path): states are
 // the env kernel's running "nibble state" (SAME-padded, FB_NIB_* in include/fbdqn.h): one byte = 2 horizontally adjacent pixels x the
 // last 4 frames (bit 4*px + f), which is exactly the 8 k-values one lane feeds to one MFMA, so the whole
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Slices sl, float *__res
 // ah*wh + (ah*wl + al*wh) / 4096 (+ al*wl / 2^24, below one fp32 rounding, dropped): three v_mfma_f32_32x32x16_f16
 // (3 x 32 cycles per 16 k), each product exact in the MFMA's fp32 accumulator, replace eight v_mfma_f32_32x32x2_f32
 // (8 x 64 cycles) while leaving the vector ALU to the address arithmetic.  NS = 1: one bf16 plane (the bf16 mode).
-// Activations travel between the layers as three bf16 planes [plane][row][channel]; the weights are
-// re-split (wsplit_kernel) whenever the parameters changed: wsp[k/8][plane][N] x 8 bf16 (16 B).
-// NS = 3: the fp32-equivalent path; NS = 1 uses the hi planes only = plain bf16 inference.
-// conv1 of that path.  The old kernel's wave re-reads all 48 KB of split weights for every tile (600 MB of
+// Activations travel between the layers as two fp16 planes (one bf16 plane in bf16 mode) [plane][row][channel]; the weights are
+// re-split whenever the parameters changed: wsp[k/8][plane][N] x 8 halves (16 B).
+// NS = 3: the fp32-equivalent path; NS = 1 uses the bf16 plane only = plain bf16 arithmetic.
+// conv1 of that path.  The small-batch kernel's wave re-reads all 32 KB of split weights for every tile (400 MB of
 // L1/L2 traffic at 1024 states); here a workgroup parks them in LDS once and its waves walk over tiles, the
 // next tile's input bytes in flight while the current one is in the MFMAs.  The vector ALU is the scarce unit here
-// (48 MFMAs per tile leave room for ~250 vector instructions): taps are immediate offsets into the SAME-padded nibble
+// (32 MFMAs per tile leave room for ~170 vector instructions): taps are immediate offsets into the SAME-padded nibble
 // image, the 2x2 pool is a max over four registers of a lane, and a quad transpose hands every lane 4 consecutive
 // channels of one pooled pixel for an 8-byte store per plane (512 B per wave, contiguous).
 // One workgroup of 12 waves per CU (3 per SIMD, <= 168 VGPRs): one copy of the weights per CU, and 12800 tiles over
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
 }
 
 // conv2 + conv3 of that path in ONE kernel, five states per workgroup (125 of its 128 MFMA rows).  A 10x10x32
-// conv2 input is 19 KB as three bf16 planes: the five of them are copied into LDS once, in full cache lines,
+// conv2 input is 12.8 KB as two fp16 planes: the five of them are copied into LDS once, in full cache lines,
 // and both convolutions gather their im2col fragments from LDS (ds_read_b128) -- the 4x (conv2) and 9x (conv3)
 // re-reads of the input and the fragment-shaped 16-byte global loads (64 cache lines per wave instruction) are gone,
 // and conv2's output never leaves the CU.  Only the weights stream: 34 chunks of 32 k (16 conv2 taps, 18 conv3
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
 
 // conv2 + conv3 for SMALL batches (training, and any forward below 256 states): one workgroup per state, the same two-plane fp16
 // arithmetic as conv23_sp_kernel (three MFMAs per fp32 product; NS = 1: one bf16 plane).  The two stand-alone fp32-MFMA kernels
-// (conv2_kernel, conv3_kernel) were two launches of ~6.5 + 7.5 us whose matrix work is under a microsecond: what they wait for is
+// (round 1's conv2_kernel, conv3_kernel) were two launches of ~6.5 + 7.5 us whose matrix work is under a microsecond: what they wait for is
 // the launch, a cold read of what the previous launch wrote, a 32-deep chain of 64-cycle fp32 MFMAs and an LDS reduction -- twice.
 // Here conv1's pooled output of ONE state (12.8 KB fp32) is split into planes in LDS once, conv2's output never leaves the CU, and
 // the 17 weight chunks of 64 k (8 for conv2's 16 taps x 32 channels, 9 for conv3's taps x 64 channels) go from L2 straight into the
@@ -1304,7 +1304,7 @@ __global__ void bump_pver_kernel(AdamDev *ad, int which) { ad->pver[which] += 1;
 __global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad->pver[which]; ad->wverc[which] = ad->pver[which]; }
 
 // ================================================================== fc1 + loss, small batches (training, < 256 states)
-// fc1 with the WHOLE reduction in one workgroup.  fc1_kernel above splits K = 1600 over 5 workgroups, which leaves five partial
+// fc1 with the WHOLE reduction in one workgroup.  Round 1's fc1_kernel split K = 1600 over 5 workgroups, which leaves five partial
 // sums per unit that only a further launch can add up -- so Q (and with it the loss and every gradient) sat two launches
 // behind fc1 (head_kernel, loss_head_kernel).  Here one workgroup owns a 16 x 16 output tile for all of K (its 8 waves split K
 // and are summed through LDS in wave order), so it can finish what depends on the complete sums: it stores the pre-activation
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
 // workgroups compute a 32 x 32 tile of dh3 (they need dhf of their 32 rows for all units: rebuilt from the fc1 sums into LDS), the
 // others eight 32 x 32 tiles of dW_fc1 in one 32-unit column block (dhf of all B rows for those 32 units).  The head's own
 // gradients (W_q, b_q, W_v, b_v, b_fc1) come from the first dW workgroup of every column block; loss / abs_err / y and the Adam
-// tick from workgroup 0.  Same arithmetic per element as loss_head_kernel + fc1_bwd_kernel.
+// tick from workgroup 0.  Same arithmetic per element as loss_head_kernel + the fp32-MFMA fc1 backward it replaced.
 struct Bw1Args {
     int algo, B, FC, A, dueling, stot, n_dx, rb;
     NetOff off;
@@ -2045,7 +2045,7 @@ __device__ __forceinline__ void adam4(float4 &P, float4 &Mv, float4 &V, const fl
 #undef FB_ADAM1
 }
 
-// W_fc1 is 91 % of the parameters and its gradient is complete once fc1_bwd_kernel has run, while the three launches
+// W_fc1 is 91 % of the parameters and its gradient is complete once the fc1 backward launch has run, while the launches
 // that follow (conv3 / conv2 / conv1 backward) neither read W_fc1 nor fill more than ~200 of the 256 CUs, and wait on
 // latency rather than on HBM.  Its Adam update therefore rides as extra workgroups at the END of the conv3 backward
 // launch (float4 range [q0, q1) of the flat parameter vector); adam_kernel at the end of the step skips that range.
@@ -2062,7 +2062,7 @@ __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan
 // ---- conv1's weight gradient on the fp16 matrix cores, one sample per workgroup.
 // dW1[(ky, kx, ci)][co] = sum over output pixels of x[4 oy + ky - 2][4 ox + kx - 2][ci] * dY[oy][ox][co], dY = the pooled gradient routed to
 // each pool's maximum.  x is u8 -- exact in fp16 -- so with dY as two fp16 planes (split2x2) the products are exact and TWO
-// v_mfma_f32_32x32x16_f16 per 16 pixels and weight-row tile replace the eight fp32 MFMAs (4x the cycles each) of conv_dw_body<1>;
+// v_mfma_f32_32x32x16_f16 per 16 pixels and weight-row tile replace the eight fp32 MFMAs (4x the cycles each) of the tiled kernel this replaced;
 // more important at these sizes, the operands come out of LDS at fixed offsets instead of through per-pixel address arithmetic
 // (that kernel spent ~750 vector instructions per 32 pixels and wave):
 //   * the sample's 80 x 80 x 4 bytes are copied once into a zero-padded LDS image [84][100][4] (conv1's SAME padding + slack for the
@@ -2071,7 +2071,7 @@ __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan
 //     wrap a row; 30 MFMA steps per sample instead of 25;
 //   * dY's fragments are the same for all 8 weight-row tiles (ky): each wave builds those of 4 steps (pool routing, split, bias sum)
 //     into LDS, then wave ky walks all 30 steps.
-// One slab per sample: B slabs (conv_dw_body<1>: B x 400 / 256), summed by the Adam kernel / slab_fold_kernel as before.
+// One slab per workgroup (two per sample), summed by the Adam kernel, through slab_fold_kernel when there are more than zmax.
 constexpr int DW1_IMG_W = 104, DW1_IMG_H = 84, DW1_IMG = DW1_IMG_H * DW1_IMG_W * 4;      // bytes; 4 zero pixels left of column 0 (16-byte rows), 2 zero rows above
 constexpr int DW1_STEPS = 30;
 
@@ -2195,7 +2195,7 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
     }
 }
 
-// ---- the conv backward of any batch in two launches (after fc1_bwd2_kernel / fc1_bwd_kernel):
+// ---- the conv backward of any batch in two launches (after fc1_bwd2_kernel / fc1_bwd_big_kernel; large batches add conv_dwg_kernel):
 //   conv_bx_kernel    B workgroups run the per-sample data-gradient chain (conv32_bx_body); beside them the conv3 weight-gradient tiles
 //                     (they need dh3 and h2 only), W_fc1's Adam span and, in fb_train_steps, the next step's random.sample
 //   conv_dw21_kernel  the conv2 weight-gradient tiles (dh2 is complete now) and conv1's (dp1), side by side
