@@ -97,7 +97,7 @@ SIGNATURES = {
 class StepBuffers(C.Structure):
     """fb_step_buffers (include/fbdqn.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("nib", "actions", "frame_bits", "reward", "terminal", "score", "idx", "s", "s2", "a", "t",
-                                           "r", "loss", "flat_grad")]
+                                           "r", "loss", "flat_grad", "isw", "isw32", "abs_err")]
 
 _lib = None
 

@@ -100,6 +100,7 @@ int fb_qnet_num_actions(fb_qnet_t h);
 int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch);
 int fb_env_num_envs(fb_env_t h);
 int fb_replay_num_envs(fb_replay_t h);
+int fb_replay_is_prioritized(fb_replay_t h);
 int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,

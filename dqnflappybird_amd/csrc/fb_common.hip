@@ -102,16 +102,22 @@ extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int b
     return rc;
 }
 
+__global__ void f64_to_f32_kernel(const double *__restrict__ x, float *__restrict__ y, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = (float)x[i];      // (what feeding float64 ISWeights to a float32 placeholder does)
+}
+
 // One step of the vectorised loop as a single host call: the five C-ABI calls of FlappyBirdDQN.py:72-76 back to back.
 extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
                            int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream) {
     FB_REQUIRE(env && replay && net && b, "fb_vec_step: NULL handle");
     FB_REQUIRE(b->nib && b->actions && b->frame_bits && b->reward && b->terminal && b->score, "fb_vec_step: NULL env buffer");
-    FB_REQUIRE(algo != FB_ALGO_PER, "fb_vec_step: prioritized replay needs the importance weights: use the separate calls");
+    const bool per = algo == FB_ALGO_PER;
+    if (per && train) FB_REQUIRE(b->isw && b->isw32 && b->abs_err, "fb_vec_step: the prioritized step needs the isw / isw32 / abs_err buffers");
     // every argument check of the calls below happens HERE, before the replay's push counter moves or anything is launched: a
     // rejected step must leave the handles exactly as they were (a counted push without its env launch would make every later
     // gather address a ring slot that was never written)
     FB_REQUIRE(algo >= 0 && algo <= 3, "fb_vec_step: unknown algo %d", algo);
+    FB_REQUIRE(per == (fb_replay_is_prioritized(replay) != 0), "fb_vec_step: algo %d and the memory's kind (uniform / prioritized) do not match", algo);
     FB_REQUIRE(n_envs == fb_env_num_envs(env) && n_envs == fb_replay_num_envs(replay), "fb_vec_step: n_envs %d does not match the env (%d) / replay (%d) handles",
                n_envs, fb_env_num_envs(env), fb_replay_num_envs(replay));
     if (train) FB_REQUIRE(b->idx && b->s && b->s2 && b->a && b->r && b->t && b->loss, "fb_vec_step: NULL training buffer");
@@ -138,10 +144,27 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
                            have_p ? &prider : nullptr, have_h ? &hrider : nullptr, stream);
     if (rc != FB_OK) return rc;
     if (!have_p) {
-        if (train && !have_s) rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
+        if (train && !have_s && !per) rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
         else rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
-    } else if (train && !have_s) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
+    } else if (train && !have_s && !per) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
     if (rc != FB_OK || !train) return rc;
+    if (per) {
+        // BrainPrioritizedReplyDQN.py:277-329 from the sample on: importance weights -> weighted loss -> |TD errors| back into the tree
+        // (fb_replay_sample above wrote the tree indices; its weights come as f64, the loss takes them as the float32 placeholder did)
+        rc = fb_replay_sample(replay, batch, nullptr, b->idx, b->isw, stream);
+        if (rc != FB_OK) return rc;
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(256), 0, fb_stream(stream), (const double *)b->isw, b->isw32, batch);
+        if (n_envs >= 256) {
+            FbRingSrc ring;
+            rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
+            if (rc == FB_OK) rc = fb_qnet_train_step_ring(net, algo, batch, &ring, b->isw32, gamma, b->loss, b->abs_err, b->flat_grad, stream);
+        } else {
+            rc = fb_replay_gather(replay, batch, b->idx, b->s, b->s2, b->a, b->r, b->t, stream);
+            if (rc == FB_OK) rc = fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, b->isw32, gamma, b->loss, b->abs_err, nullptr, b->flat_grad, stream);
+        }
+        if (rc != FB_OK) return rc;
+        return fb_replay_update_priorities(replay, batch, b->idx, b->abs_err, nullptr, stream);
+    }
     // No gather (256 envs or more).  The train step's first launch reads the sampled transitions' 1-bit frames in the ring itself
     // (conv trunk per state) and leaves a / r / t behind; the split conv planes it needs are current because the acting forward above
     // has just refreshed them.  (b->s / b->s2 stay untouched then.)

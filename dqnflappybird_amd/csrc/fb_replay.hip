@@ -573,10 +573,16 @@ extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_repla
     P.cap = capacity; P.n_envs = n_envs; P.kind = kind;
     P.t_f = (int)((capacity + n_envs - 1) / n_envs) + 6;
     const size_t slots = (size_t)P.t_f * n_envs;
+    // (the ring and its rows start as zeros: slots that have never been pushed to hold nothing of an earlier allocation, and equal
+    // memories save equal checkpoint blobs)
     hipError_t e = hipMalloc(&P.bits, slots * WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(P.bits, 0, slots * WORDS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&P.act, slots);
+    if (e == hipSuccess) e = hipMemset(P.act, 0, slots);
     if (e == hipSuccess) e = hipMalloc(&P.rew, slots * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(P.rew, 0, slots * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&P.term, slots);
+    if (e == hipSuccess) e = hipMemset(P.term, 0, slots);
     if (e == hipSuccess) e = hipMalloc(&P.dev, sizeof(ReplayDev));
     if (e == hipSuccess) e = hipMemset(P.dev, 0, sizeof(ReplayDev));
     if (e == hipSuccess) e = hipMalloc(&P.mt, sizeof(FbMT));
@@ -692,6 +698,8 @@ extern "C" int fb_replay_push_sample(fb_replay_t h, const uint8_t *frames, const
 }
 
 int fb_replay_num_envs(fb_replay_t h) { return h ? h->P.n_envs : 0; }
+
+int fb_replay_is_prioritized(fb_replay_t h) { return h && h->P.kind == FB_REPLAY_PER; }
 
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
     ReplayParams &P = h->P;
@@ -893,7 +901,9 @@ extern "C" int fb_replay_save_state(fb_replay_t h, void *blob_host, size_t bytes
     char *o = (char *)blob_host + sizeof(hd);
     for (int i = 0; i < n; i++) {
         FB_CHECK_HIP(hipMemcpy(o, parts[i].dev, parts[i].bytes, hipMemcpyDeviceToHost));
-        o += (parts[i].bytes + 15) & ~(size_t)15;
+        const size_t padded = (parts[i].bytes + 15) & ~(size_t)15;
+        memset(o + parts[i].bytes, 0, padded - parts[i].bytes);          // (alignment gaps: equal memories give equal blobs)
+        o += padded;
     }
     return FB_OK;
 }

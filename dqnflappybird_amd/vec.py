@@ -413,8 +413,9 @@ class TrainSteps:
 
 
 class VecStep:
-    """One whole step of the vectorised loop (FlappyBirdDQN.py:72-76 for N envs, uniform replay) as a single
-    host call, fb_vec_step: getAction -> frame_step -> store + random.sample -> minibatch -> _trainQNetwork.
+    """One whole step of the vectorised loop (FlappyBirdDQN.py:72-76 for N envs) as a single
+    host call, fb_vec_step: getAction -> frame_step -> store + sample -> minibatch -> _trainQNetwork (prioritized memories: ->
+    Memory.batch_update as well).
     The same C-ABI calls in the same order as the separate VecGameState / VecReplay / QNet methods (identical
     results); the pointers are bound once, so the interpreter spends one ctypes call per step instead of five."""
 
@@ -422,8 +423,8 @@ class VecStep:
         """flat_grad: export the gradient instead of applying Adam (data parallel; the caller all-reduces and calls net.apply_adam).
         dist: a dist.NativeDP -- then the call is fb_vec_step_dp: the step, the all-reduce of flat_grad through the library's own
         RCCL communicator (overlapped with the conv backward) and Adam, all in the one host call; mean_loss divides by the world size."""
-        if replay.prioritized or algo == "per":
-            raise ValueError("VecStep is for uniform replay (PER needs the importance weights: use the separate calls)")
+        if replay.prioritized != (algo == "per"):
+            raise ValueError("algo 'per' goes with a prioritized memory, every other algo with a uniform one")
         if dist is not None and flat_grad is None:
             raise ValueError("VecStep(dist=...) needs the flat_grad buffer the gradient is reduced in")
         self.dist, self.mean_loss = dist, int(bool(mean_loss))
@@ -441,9 +442,14 @@ class VecStep:
         self.r = torch.empty(B, dtype=torch.float32, device=dev)
         self.t = torch.empty(B, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        per = algo == "per"                                # Memory.sample's weights (f64, and as the float32 placeholder takes them), |TD errors|
+        self.isw = torch.zeros(B, dtype=torch.float64, device=dev) if per else None
+        self.isw32 = torch.zeros(B, dtype=torch.float32, device=dev) if per else None
+        self.abs_err = torch.zeros(B, dtype=torch.float32, device=dev) if per else None
         p = lambda x: None if x is None else x.data_ptr()
         self.buf = L.StepBuffers(p(env.nib), p(self.actions), p(env.frame_bits), p(env.reward), p(env.terminal), p(env.score),
-                                 p(self.idx), p(self.s), p(self.s2), p(self.a), p(self.t), p(self.r), p(self.loss), p(flat_grad))
+                                 p(self.idx), p(self.s), p(self.s2), p(self.a), p(self.t), p(self.r), p(self.loss), p(flat_grad),
+                                 p(self.isw), p(self.isw32), p(self.abs_err))
 
     def __call__(self, epsilon, seed=0, step=0, train=True):
         """-> actions uint8[N] (device); rewards / terminals / scores are the env's tensors, loss is self.loss."""

@@ -18,6 +18,7 @@ class HipVecBackend:
     same five factories, so that the rank logic below -- seed offsets, gradient averaging, target-sync placement -- runs
     in the world-size-2 gloo tests without a GPU; the product never uses anything else than this class.)"""
     name = "hip-gfx950"
+    per_one_step = True                                      # fb_vec_step runs the prioritized step too (store, Memory.sample, train, batch_update)
 
     def env(self, n_envs, seed):
         from .vec import VecGameState
@@ -111,13 +112,13 @@ class VecBrain:
         self.stats = self.env.track_stats()                  # [episodes, score sum, score max, pipes passed], kept by the env kernel
         self.last_loss = None
         self.dtype = "f32"
-        # uniform replay: the whole step is one host call (fb_vec_step), with the head, random.sample and the Memory append
-        # riding in the env launch; PER keeps the separate calls (its sample returns the importance weights)
+        # the whole step is one host call (fb_vec_step): uniform replay with the head, random.sample and the Memory append riding in the
+        # env launch; prioritized replay with store -> Memory.sample -> weighted train -> batch_update as launches of the same call
         self.native = None
         if self.grad is not None and algo != "per" and hasattr(be, "native"):
             self.native = be.native(rank, world)
-        if algo == "per":
-            self.one_step = None
+        if algo == "per" and not getattr(be, "per_one_step", False):
+            self.one_step = None                             # (a backend without the fused prioritized step: the separate calls below)
         elif self.native is not None:
             self.one_step = be.step(self.env, self.replay, self.net, batch, algo, gamma, self.grad, dist=self.native, mean_loss=MEAN_LOSS[algo])
         else:

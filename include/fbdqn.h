@@ -274,7 +274,7 @@ int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int algo, int batc
 const char *fb_qnet_kernel_name(int kernel);
 
 /* ------------------------------------------------------------------ one whole step of the vectorised loop
- * FlappyBirdDQN.py:72-76 for N envs in ONE call (uniform replay): getAction (fb_qnet_act_nib) -> frame_step
+ * FlappyBirdDQN.py:72-76 for N envs in ONE call: getAction (fb_qnet_act_nib) -> frame_step
  * (fb_env_step, packed frames) -> store + random.sample (fb_replay_push_sample) -> minibatch (fb_replay_gather)
  * -> _trainQNetwork (fb_qnet_train_step).  The results of exactly those calls in that order on `stream`.  It saves the
  * host's per-call overhead between launches (the GPU otherwise idles ~15 us per step waiting for the interpreter) and
@@ -283,6 +283,8 @@ const char *fb_qnet_kernel_name(int kernel);
  * else keeps its own launch), bit-identical to the separate calls.
  * With >= 256 envs the step skips the gather launch as well: the train step's first kernel reads the sampled
  * transitions' 1-bit frames in the ring itself (fb_train_from_replay below) -- same results, b->s / b->s2 stay untouched.
+ * A prioritized memory (BrainPrioritizedReplyDQN.py:277-329) runs store -> Memory.sample -> train with the importance weights ->
+ * Memory.batch_update in the same call (fb_replay_push, fb_replay_sample, fb_train_from_replay, fb_replay_update_priorities: no riders).
  * All pointers [dev], caller owned; nib is the buffer given to fb_env_set_nib_buffer.  train = 0 stops after the
  * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
  * fb_qnet_apply_adam). */
@@ -295,6 +297,9 @@ typedef struct {
     uint8_t *s, *s2, *a, *t; float *r;              /* gathered minibatch: u8[B,80,80,4] x2, u8[B], u8[B], f32[B] */
     float *loss;                                    /* f32[1] out */
     float *flat_grad;                               /* f32[n_params] or NULL */
+    /* prioritized replay (algo = FB_ALGO_PER) only, else NULL: Memory.sample's importance weights as it returns them (f64[B]) and as the
+     * float32 placeholder takes them (f32[B]), and the |TD errors| Memory.batch_update receives (f32[B]) */
+    double *isw; float *isw32; float *abs_err;
 } fb_step_buffers;
 int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo, int batch,
                 float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);

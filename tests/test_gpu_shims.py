@@ -372,6 +372,45 @@ def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
 
 
+def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda):
+    """fb_vec_step on a prioritized memory (BrainPrioritizedReplyDQN.py:277-329 for N envs in one host call: act -> env -> Memory.store ->
+    Memory.sample -> weighted train -> Memory.batch_update) == the separate calls, bit for bit: actions, tree indices, importance
+    weights, loss and |TD errors| step by step, parameters, the raw tree bytes and beta at the end (reference-order tree)."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep, train_from_replay
+    N, B, steps = 256, 32, 30
+
+    def make():
+        env, rep, net = VecGameState(N, seed=5), VecReplay(8192, N, prioritized=True), QNet(max_batch=N)
+        rep.seed(9, "numpy"); net.init_params(3, which=0); net.init_params(4, which=1)
+        nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
+        return env, rep, net, nib
+
+    e1, r1, n1, nib1 = make()
+    e2, r2, n2, nib2 = make()
+    one = VecStep(e2, r2, n2, B, "per")
+    for step in range(steps):
+        train = step >= 8
+        a1 = n1.act_nib(nib1, 0.05, seed=1, step=step)
+        e1.frame_step(a1, want_u8=False)
+        r1.push(e1.frame_bits, a1, e1.reward, e1.terminal)
+        if train:
+            idx, isw = r1.sample(B)
+            loss, a_, r_, t_, ae = train_from_replay(r1, n1, "per", idx, isw=isw, want_abs_err=True)
+            r1.update_priorities(idx, abs_err=ae)
+        a2 = one(0.05, seed=1, step=step, train=train)
+        assert torch.equal(a1, a2), step
+        if train:
+            assert torch.equal(idx, one.idx) and torch.equal(isw, one.isw), step
+            assert torch.equal(loss, one.loss) and torch.equal(ae, one.abs_err), step
+    assert (e1.get_state() == e2.get_state()).all() and torch.equal(nib1, nib2)
+    assert torch.equal(n1.store_params(), n2.store_params())
+    b1, b2 = r1.state_blob(), r2.state_blob()
+    assert np.array_equal(np.asarray(b1), np.asarray(b2))             # ring, rows, counters, generator, SumTree + max / min heaps, beta
+    with pytest.raises(ValueError):
+        VecStep(e2, r2, n2, B, "dqn")                                  # a uniform algo on a prioritized memory
+
+
 def test_train_from_replay_prioritized_equals_the_separate_calls(torch_cuda):
     """The prioritized step through fb_train_from_replay (SumTree leaf indices, importance weights in, |TD errors| out) ==
     fb_replay_gather + fb_qnet_train_step(isw) + the same priorities update, bit for bit over several sample / train / update rounds."""
