@@ -289,6 +289,7 @@ constexpr int PS_CHUNK = 4096;               // leaves per pass (their changes l
 
 __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int count) {
     __shared__ double chg[PS_CHUNK];
+    __shared__ double sibv[4 * MAXH];       // min-heap values of the untouched children of the edge nodes, fetched up front
     __shared__ long long lvl_lo[MAXH];
     __shared__ int lvl_off[MAXH + 1];
     const int tid = threadIdx.x;
@@ -315,6 +316,13 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
             P.tree[leaf] = max_p; P.maxt[leaf] = max_p; P.mint[leaf] = max_p;
         }
         if (tid < D) lvl_lo[tid] = anc(leaf_lo, D, tid);
+        if (tid >= 512 && tid < 512 + 4 * D) {                   // (level d, edge e, child k): one load each, all in flight together --
+            const int q = tid - 512, d = q >> 2, e = (q >> 1) & 1, k = (q & 1) + 1;      // the walk in 3) then never waits for memory
+            const long long a = e ? anc(leaf_hi, D, d) : anc(leaf_lo, D, d), c = 2 * a + k;
+            const int sh1 = D - d - 1;
+            const long long Lc = ((c + 1) << sh1) - 1, Rc = ((c + 2) << sh1) - 2;
+            sibv[q] = (Rc < leaf_lo || Lc > leaf_hi) ? P.mint[c] : 0.0;
+        }
         if (tid == 0) {                                          // node tasks flattened root first (the long ones land on different threads)
             int off = 0;
             for (int d = 0; d < D; d++) { lvl_off[d] = off; off += (int)(anc(leaf_hi, D, d) - anc(leaf_lo, D, d)) + 1; }
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
                         const long long c = 2 * a + k;
                         const long long Lc = ((c + 1) << sh1) - 1, Rc = ((c + 2) << sh1) - 2;
                         double cv;
-                        if (Rc < leaf_lo || Lc > leaf_hi) cv = P.mint[c];                    // untouched: the stored value stands
+                        if (Rc < leaf_lo || Lc > leaf_hi) cv = sibv[(d * 2 + e) * 2 + (k - 1)];  // untouched: the stored value stands (fetched above)
                         else if (Lc >= leaf_lo && Rc <= leaf_hi) cv = max_p;                 // all new
                         else cv = c == clo ? m_lo : m_hi;                                     // the level below's edge node
                         (void)chi;
