@@ -372,7 +372,8 @@ def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
 
 
-def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda):
+@pytest.mark.parametrize("dp", [False, True])
+def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda, dp):
     """fb_vec_step on a prioritized memory (BrainPrioritizedReplyDQN.py:277-329 for N envs in one host call: act -> env -> Memory.store ->
     Memory.sample -> weighted train -> Memory.batch_update) == the separate calls, bit for bit: actions, tree indices, importance
     weights, loss and |TD errors| step by step, parameters, the raw tree bytes and beta at the end (reference-order tree)."""
@@ -388,7 +389,10 @@ def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda):
 
     e1, r1, n1, nib1 = make()
     e2, r2, n2, nib2 = make()
-    one = VecStep(e2, r2, n2, B, "per")
+    # dp: the data-parallel form of the same step -- the gradient is exported, the priorities are updated from the local |TD errors|
+    # inside the call, Adam follows from outside (after the all-reduce a multi-rank run would put in between)
+    grad = torch.zeros(n2.n_params, dtype=torch.float32, device="cuda") if dp else None
+    one = VecStep(e2, r2, n2, B, "per", flat_grad=grad)
     for step in range(steps):
         train = step >= 8
         a1 = n1.act_nib(nib1, 0.05, seed=1, step=step)
@@ -399,6 +403,8 @@ def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda):
             loss, a_, r_, t_, ae = train_from_replay(r1, n1, "per", idx, isw=isw, want_abs_err=True)
             r1.update_priorities(idx, abs_err=ae)
         a2 = one(0.05, seed=1, step=step, train=train)
+        if train and dp:
+            n2.apply_adam(grad)
         assert torch.equal(a1, a2), step
         if train:
             assert torch.equal(idx, one.idx) and torch.equal(isw, one.isw), step
