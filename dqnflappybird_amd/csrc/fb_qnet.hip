@@ -2568,7 +2568,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
     void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->slabs1, h->adam, h->p1, h->amax, h->h2,
-                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1};
+                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1, h->ring_fo};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return FB_OK;
