@@ -116,21 +116,15 @@ def main():
     # train from the ring; the same launches as the separate calls, without the interpreter between them).
     # N > 1: fb_vec_step_dp -- the same step exporting its gradient, the all-reduce (sum loss, BrainDQN.py:162 -> plain sum) through the
     # library's own RCCL communicator in two pieces (W_fc1 / head part on a side stream behind the fc1 backward launch, conv part on the
-    # step's stream) and Adam, still one host call.  FB_DP_NATIVE=0 falls back to torch.distributed's all-reduce between fb_vec_step
-    # and fb_qnet_apply_adam (FB_DP_OVERLAP=1: in two pieces, dist.OverlappedAllReduce).
-    from dqnflappybird_amd.dist import NativeDP, OverlappedAllReduce
+    # step's stream) and Adam, still one host call -- with FB_DP_NATIVE=1 (opt-in: that path has never run at world size > 1).  Default:
+    # torch.distributed's all-reduce between fb_vec_step and fb_qnet_apply_adam (FB_DP_OVERLAP=1: in two pieces, dist.OverlappedAllReduce).
+    from dqnflappybird_amd.dist import NativeDP, NativeUnavailable, OverlappedAllReduce, native_wanted
     native = None
-    if (world > 1 or force_dp) and backend == "nccl" and os.environ.get("FB_DP_NATIVE", "1") != "0":
-        try:
+    if (world > 1 or force_dp) and backend == "nccl" and (native_wanted() or force_dp):
+        try:                                                 # all ranks succeed, or all ranks get NativeUnavailable (dist.NativeDP)
             native = NativeDP(rank, world)
-        except Exception as e:                               # pragma: no cover  (no RCCL to load, communicator refused, ...)
-            print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({type(e).__name__}: {e})", file=sys.stderr)
-        if world > 1:                                        # every rank takes the same path: all of them native, or none
-            ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0 and native is not None:
-                native.close()
-                native = None
+        except NativeUnavailable as e:                       # pragma: no cover  (no RCCL to load on some rank)
+            print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({e}); torch.distributed's all-reduce", file=sys.stderr)
     one_step = VecStep(env, replay, net, BATCH, "dqn", flat_grad=grad, dist=native)
     want_overlap = os.environ.get("FB_DP_OVERLAP", "0") == "1"
     reduce_grad = OverlappedAllReduce(net, grad, mean_loss=False) if world > 1 and backend == "nccl" and want_overlap and native is None else None

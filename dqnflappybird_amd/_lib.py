@@ -78,6 +78,7 @@ SIGNATURES = {
     "fb_train_steps": [_vp, _vp, _i, _i, _i] + [_vp] * 7 + [_d, _vp],
     "fb_qnet_sync_target": [_vp, _vp],
     "fb_qnet_profile_kernel": [_vp, _i, _i, _i, _i] + [_vp] * 7,
+    "fb_dist_probe": [C.c_char_p],
     "fb_dist_unique_id": [C.c_char_p, _vp],
     "fb_dist_create": [C.c_char_p, _i, _i, _vp],
     "fb_dist_destroy": [_vp],

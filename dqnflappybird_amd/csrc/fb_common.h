@@ -83,9 +83,11 @@ struct FbRingSrc { FbGatherCtx c; long long steps; const long long *idx; uint8_t
 int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a, float *r, uint8_t *t, FbRingSrc *out);
 // fb_qnet_train_step on such a minibatch (isw / abs_err: the prioritized step's importance weights in, |TD errors| out; else NULL).  The split conv planes of both nets must be current: true
 // after an acting forward of >= 256 states in the same stream order (fb_vec_step), which is the only caller.
+// rider: random.sample for the NEXT step in the conv3 backward launch (fb_train_steps), or NULL.
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, const float *isw, double gamma, float *loss,
-                            float *abs_err, float *flat_grad, void *stream);
+                            float *abs_err, float *flat_grad, void *stream, const FbSampleRider *rider = nullptr);
 int fb_qnet_refresh_planes(fb_qnet_t h, void *stream);      // re-split whichever net's planes are stale (decided on the device)
+int fb_qnet_refresh_conv_planes(fb_qnet_t h, void *stream); // the same for the W_conv2 / W_conv3 planes alone (all the ring-fed conv trunk needs)
 int fb_qnet_profile_ring(fb_qnet_t h, int kernel, int reps, int algo, int batch, const FbRingSrc *ring, float *loss, void *stream);
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
 // into the ring slot of the coming push (bits: slot of env 0's frame, +100 words per env; act / rew / term: row of the
@@ -95,6 +97,9 @@ struct FbPushRider { unsigned long long *bits; uint8_t *act; float *rew; uint8_t
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream);
 int fb_qnet_num_actions(fb_qnet_t h);
+void *fb_qnet_get_grad_event(fb_qnet_t h);                 // the event fb_qnet_set_grad_event installed, or NULL
+// the event the LAST gradient-exporting train step recorded behind its fc1 backward launch (NULL: none was recorded); reading clears it
+void *fb_qnet_take_grad_event_recorded(fb_qnet_t h);
 // argument checks fb_vec_step makes BEFORE any counter moves or any launch goes out (0 = fine, else the error code with
 // fb_last_error set): the batch the train step would reject / the env count the acting forward would reject
 int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch);

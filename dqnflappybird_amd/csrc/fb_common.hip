@@ -1,5 +1,6 @@
 // fb_common.hip -- error channel, version, host-side MT19937 seeding.
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <stdlib.h>
 #include <unistd.h>
@@ -18,27 +19,41 @@ int fb_set_error(int code, const char *fmt, ...) {
 extern "C" const char *fb_last_error(void) { return fb_err_buf; }
 
 // Diagnostics: a process that dies in abort() (the HIP / ROCr runtimes do that on fatal errors, sometimes without a message) leaves its
-// native call stack on stderr first.  Async-signal-safe calls only; chains to whatever handler was installed before (Python's
-// faulthandler prints the interpreter's stack after this one).
+// native call stack on stderr first -- and, when FB_ABORT_LOG names a file, in that file too: a test runner that captures file
+// descriptor 2 (pytest's default) takes the runtime's own message and this trace down with it when the process dies.
+// Async-signal-safe calls only; chains to whatever handler was installed before (Python's faulthandler prints the interpreter's
+// stack after this one).  Idempotent: a second call keeps the first call's saved handler (saving our own handler as the
+// "previous" one would make the handler chain to itself).
 static struct sigaction fb_prev_abrt;
+static bool fb_abrt_installed = false;
+static int fb_abrt_log_fd = -1;
 static void fb_abort_backtrace(int sig, siginfo_t *info, void *ctx) {
     static const char msg[] = "\n[libfbdqn] SIGABRT: native stack of the aborting thread\n";
-    if (write(2, msg, sizeof(msg) - 1) < 0) {}
     void *frames[64];
     const int n = backtrace(frames, 64);
-    backtrace_symbols_fd(frames, n, 2);
-    if (fb_prev_abrt.sa_flags & SA_SIGINFO) { if (fb_prev_abrt.sa_sigaction) fb_prev_abrt.sa_sigaction(sig, info, ctx); }
+    const int fds[2] = {2, fb_abrt_log_fd};
+    for (int k = 0; k < 2; k++) {
+        if (fds[k] < 0) continue;
+        if (write(fds[k], msg, sizeof(msg) - 1) < 0) {}
+        backtrace_symbols_fd(frames, n, fds[k]);
+    }
+    if (fb_prev_abrt.sa_flags & SA_SIGINFO) { if (fb_prev_abrt.sa_sigaction && fb_prev_abrt.sa_sigaction != fb_abort_backtrace) fb_prev_abrt.sa_sigaction(sig, info, ctx); }
     else if (fb_prev_abrt.sa_handler != SIG_DFL && fb_prev_abrt.sa_handler != SIG_IGN) fb_prev_abrt.sa_handler(sig);
 }
 extern "C" int fb_debug_abort_backtrace(void) {
+    if (fb_abrt_installed) return FB_OK;
     void *warm[4];
     (void)backtrace(warm, 4);                        // (loads libgcc now: the first call allocates, which a signal handler must not)
+    const char *path = getenv("FB_ABORT_LOG");
+    if (path && *path) fb_abrt_log_fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_sigaction = fb_abort_backtrace;
     sa.sa_flags = SA_SIGINFO | SA_RESETHAND;
     sigemptyset(&sa.sa_mask);
-    return sigaction(SIGABRT, &sa, &fb_prev_abrt) == 0 ? FB_OK : fb_set_error(FB_ERR_STATE, "sigaction(SIGABRT) failed");
+    if (sigaction(SIGABRT, &sa, &fb_prev_abrt) != 0) return fb_set_error(FB_ERR_STATE, "sigaction(SIGABRT) failed");
+    fb_abrt_installed = true;
+    return FB_OK;
 }
 extern "C" int fb_version(void) { return 100; }
 
@@ -75,16 +90,34 @@ void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int key_length) {
     s->idx = 624;
 }
 
-// n x (random.sample -> minibatch -> _trainQNetwork) on a memory that is not being pushed to, as one host call.  Only the
-// first draw and the first gather get launches of their own: the draw for step i + 1 rides in step i's conv3 backward launch
-// (it needs the generator and len(memory), nothing of step i) and the gather of step i + 1 in step i's Adam launch (nothing of
-// step i reads the minibatch buffers by then): sampler and gather leave the chain of dependent launches.
-// idx holds two index buffers used alternately; the indices of step i end up in idx[(i & 1) * batch ..).
+// n x (random.sample -> minibatch -> _trainQNetwork) on a memory that is not being pushed to, as one host call.  Each step is the six
+// launches of the ring-fed train step (conv trunk of the 2B states straight from the 1-bit frame ring -> fc1 -> loss + fc1 backward ->
+// conv data gradients -> conv weight gradients -> Adam): no gather, no u8 minibatch.  Only the first draw gets a launch of its own: the
+// draw for step i + 1 rides in step i's conv3 backward launch (it needs the generator and len(memory), nothing of step i).  What lets
+// a step start with the trunk: the fused Adam launch leaves the split planes of W_conv1 / W_conv2 / W_conv3 behind
+// (adam_fused_kernel), so they are current without an acting forward in between; whatever was stale on entry is re-split once here.
+// idx holds two index buffers used alternately; the indices of step i end up in idx[(i & 1) * batch ..).  s / s2 (the u8 minibatch
+// of the gathered form) are only written when FB_TRAIN_STEPS_GATHER=1 selects that form (A/B knob: 7 launches per step).
 extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int batch, int n_steps, int64_t *idx, uint8_t *s,
                               uint8_t *s2, uint8_t *a, float *r, uint8_t *t, float *loss, double gamma, void *stream) {
     FB_REQUIRE(replay && net && idx && s && s2 && a && r && t && loss && n_steps >= 1, "fb_train_steps: bad argument");
     FB_REQUIRE(algo != FB_ALGO_PER, "fb_train_steps: prioritized replay needs the importance weights: use the separate calls");
+    static const bool gathered_form = getenv("FB_TRAIN_STEPS_GATHER") && atoi(getenv("FB_TRAIN_STEPS_GATHER")) == 1;
     int rc = fb_replay_sample(replay, batch, nullptr, idx, nullptr, stream);
+    if (!gathered_form) {
+        if (rc == FB_OK) rc = fb_qnet_refresh_conv_planes(net, stream);
+        for (int i = 0; rc == FB_OK && i < n_steps; i++) {
+            int64_t *cur = idx + (size_t)(i & 1) * batch, *nxt = idx + (size_t)((i + 1) & 1) * batch;
+            FbRingSrc ring;
+            rc = fb_replay_ring_src(replay, batch, cur, a, r, t, &ring);
+            if (rc != FB_OK) break;
+            FbSampleRider srider;
+            const int rides = i + 1 < n_steps && fb_replay_sample_rider(replay, batch, nxt, &srider, 0);
+            rc = fb_qnet_train_step_ring(net, algo, batch, &ring, nullptr, gamma, loss, nullptr, nullptr, stream, rides ? &srider : nullptr);
+            if (rc == FB_OK && i + 1 < n_steps && !rides) rc = fb_replay_sample(replay, batch, nullptr, nxt, nullptr, stream);
+        }
+        return rc;
+    }
     bool gathered = false;                               // the minibatch of step i is already in s / s2 / a / r / t
     for (int i = 0; rc == FB_OK && i < n_steps; i++) {
         int64_t *cur = idx + (size_t)(i & 1) * batch, *nxt = idx + (size_t)((i + 1) & 1) * batch;

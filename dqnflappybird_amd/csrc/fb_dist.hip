@@ -64,6 +64,10 @@ struct fb_dist {
     int overlap;                     // 0 (default): one all-reduce of the whole vector on the step's stream; 1: the two-piece schedule above
 };
 
+// rank-local and non-collective: can this process load RCCL at all?  Every rank calls it BEFORE the ranks agree on the native path
+// (dist.NativeDP.agree): what can fail alone must fail before anything collective starts.
+extern "C" int fb_dist_probe(const char *librccl_path) { return load_rccl(librccl_path); }
+
 extern "C" int fb_dist_unique_id(const char *librccl_path, uint8_t *id128) {
     FB_REQUIRE(id128, "fb_dist_unique_id: NULL argument");
     int rc = load_rccl(librccl_path);
@@ -115,6 +119,11 @@ static int reduce_and_apply(fb_dist_t d, fb_qnet_t net, float *g, int mean, hipS
         if (mean && d->world > 1) hipLaunchKernelGGL(div_kernel, dim3(256), dim3(256), 0, st, g, (long long)n, (float)d->world);
         return fb_qnet_apply_adam(net, g, st);
     }
+    // d->grad_ready must have been recorded by THIS step (behind its fc1 backward launch).  A step that ran without the event installed
+    // on the net (fb_qnet_set_grad_event forgotten before fb_qnet_train_step / fb_train_from_replay) has not recorded it, and the side
+    // stream would wait on a stale, long completed event and reduce the tail while the backward pass still writes it.  Recording it here
+    // in that case is always safe -- it only gives the overlap away for this step.
+    if (fb_qnet_take_grad_event_recorded(net) != (void *)d->grad_ready) FB_CHECK_HIP(hipEventRecord(d->grad_ready, st));
     FB_CHECK_HIP(hipStreamWaitEvent(d->side, d->grad_ready, 0));
     FB_CHECK_NCCL(rccl.AllReduce(g + split, g + split, (size_t)(n - split), ncclFloat, ncclSum, d->comm, d->side));
     if (mean && d->world > 1) hipLaunchKernelGGL(div_kernel, dim3(256), dim3(256), 0, d->side, g + split, n - split, (float)d->world);
@@ -134,10 +143,11 @@ extern "C" int fb_dist_set_overlap(fb_dist_t d, int overlap) {
 extern "C" int fb_vec_step_dp(fb_dist_t d, fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
                               int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, int mean_loss, void *stream) {
     FB_REQUIRE(d && b && (!train || b->flat_grad), "fb_vec_step_dp: NULL handle / flat_grad buffer");
+    void *prev = fb_qnet_get_grad_event(net);          // (an event the caller installed for its own schedule is put back afterwards)
     int rc = fb_qnet_set_grad_event(net, d->overlap ? d->grad_ready : nullptr);
     if (rc != FB_OK) return rc;
     rc = fb_vec_step(env, replay, net, b, n_envs, algo, batch, epsilon, seed, step, train, gamma, stream);
-    (void)fb_qnet_set_grad_event(net, nullptr);
+    (void)fb_qnet_set_grad_event(net, prev);
     if (rc != FB_OK || !train) return rc;
     return reduce_and_apply(d, net, b->flat_grad, mean_loss, fb_stream(stream));
 }

@@ -141,8 +141,9 @@ __device__ __forceinline__ void split3x2(float x0, float x1, uint32_t &hi, uint3
 
 // ---- fp32 as TWO fp16 numbers.  x = h + l / 4096 with h = fp16(x) and l = fp16((x - h) * 4096), both rounded to nearest:
 // |x - h| <= 2^-12 |x| and the second rounding leaves 2^-12 of that, so the pair carries x to 2^-24 relative -- fp32's own
-// precision (2 x 11 significand bits plus the two roundings' sign bits); the scale keeps l in h's exponent range instead of
-// fp16's subnormals.  A product a * w is then ah*wh + (ah*wl + al*wh) / 4096 + (al*wl) / 2^24: every fp16 x fp16 product is
+// precision (2 x 11 significand bits plus the two roundings' sign bits) -- FOR 2^-14 <= |x| < 65504, fp16's normal range; the
+// scale keeps l in h's exponent range instead of fp16's subnormals.  (Gradient operands are brought into that range by an exact
+// power-of-two pre-scale, see pow2_scale below.)  A product a * w is then ah*wh + (ah*wl + al*wh) / 4096 + (al*wl) / 2^24: every fp16 x fp16 product is
 // exact in the MFMA's fp32 accumulator, the last term is below one fp32 rounding and is dropped.  THREE v_mfma_f32_32x32x16_f16
 // per 16 k (one into the main accumulator, two into a second one that is folded in with an exact power-of-two scale at the end)
 // replace the SIX bf16 products of the hi/mid/lo split this path used before (three bf16 planes, 8 bits each) at the same
@@ -165,6 +166,44 @@ __device__ __forceinline__ f32x16 mfma_b(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 constexpr uint32_t F16_255 = 0x5BF8u;        // 255.0 as fp16 (a lit pixel)
+
+// ---- range of the two-plane form, and the power-of-two pre-scale that keeps GRADIENT operands inside it.
+// The 2^-24 above holds while |x| >= 2^-14 (6.1e-5), fp16's smallest normal number: below it h is subnormal, the pair degrades
+// linearly towards an ABSOLUTE error floor of ~7e-12, and values above 65504 overflow.  Weights and activations of this network live
+// well inside that range (and a weight below 6e-5 still only errs by 7e-12 absolute, 1e-9 of a typical weight).  Gradients do not:
+// with the mean losses (/ B, PER also x isw) and the reference's sigma = 0.01 weights, dh3 / dh2 / dp1 are 1e-6 .. 1e-8 throughout a
+// run.  Every gradient operand is therefore multiplied by an exact power of two S before the split -- chosen from the maximum
+// magnitude of the operand block (one sample, or one group of 16 samples, or the whole dhf matrix), so that the maximum lands in
+// [2^10, 2^11) -- and the accumulator is multiplied by 1 / S in the epilogue, next to F16_LO_UNSCALE: both exact, so the result is
+// that of unscaled arithmetic with operands of full two-plane precision.  Elements more than 2^24 below their block's maximum lose
+// precision progressively; they are below one fp32 rounding of the sums the maximum takes part in.
+struct Pow2 { float s, inv; };
+__device__ __forceinline__ Pow2 pow2_scale(float maxabs) {
+    const int e = (int)((__float_as_uint(maxabs) >> 23) & 255u);      // biased exponent (0: zero / subnormal maximum)
+    int sb = 264 - e;                                                  // 127 + (10 - (e - 127))
+    sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);                           // S and 1 / S both normal fp32 numbers
+    Pow2 r;
+    r.s = __uint_as_float((uint32_t)sb << 23); r.inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+    return r;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// maximum over the workgroup's first NW waves of a per-thread non-negative value: one LDS word per wave (sx[0 .. NW)), written here,
+// read after the caller's barrier by wg_max_read
+__device__ __forceinline__ void wg_max_write(float v, float *sx, int wave, int lane) {
+    v = wave_max(v);
+    if (lane == 0) sx[wave] = v;
+}
+template <int NW>
+__device__ __forceinline__ float wg_max_read(const float *sx) {
+    float m = sx[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) m = fmaxf(m, sx[w]);
+    return m;
+}
 
 // W_conv1 in that form: w1s[part][ky][kq][h][co][8] fp16, part 0 = h, part 1 = l (conv1's u8 input is exact in fp16, so conv1 needs
 // only x*wh and x*wl: two MFMAs per 16 k)
@@ -1133,6 +1172,7 @@ struct LossArgs {
     const uint8_t *act; const float *rew; const uint8_t *term; const float *isw;
     double gamma;
     float *grad, *dhf, *loss, *abs_err, *y_out;
+    float *gmax;                    // [FC / 16]: every workgroup's maximum |dhf| (fc1_bwd_big_kernel derives its operand pre-scale from them)
     AdamDev *adam; int tick;
 };
 
@@ -1146,13 +1186,13 @@ struct LossArgs {
 // nothing is loaded behind the barrier, and no load sits under a branch (clamped addresses + selects; AT = the
 // number of actions at compile time, MAXA = read it from L.A).
 template <int AT>
-__device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[MAXA], float *dv, float *lterm, float (*part)[16][MAXA + 2]) {
+__device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[MAXA], float *dv, float *lterm, float (*part)[16][MAXA + 2], float *wmax) {
     const int tid = threadIdx.x, B = L.B, A = AT == MAXA ? L.A : AT;
     const bool lead = blockIdx.x == 0;
     const float *P = L.params;
     const int jl = tid & 15, bg = tid >> 4, jj = blockIdx.x * 16 + jl;
     // ---- everything this thread needs from memory
-    float gw[AT], wrow[AT], gv = 0.f, gb = 0.f;
+    float gw[AT], wrow[AT], gv = 0.f, gb = 0.f, dmax = 0.f;
 #pragma unroll
     for (int a = 0; a < AT; a++) { gw[a] = 0.f; wrow[a] = P[L.off.wq + jj * A + (a < A ? a : 0)]; }
     float wvj = P[(L.dueling ? L.off.wv : L.off.bf1) + jj];
@@ -1261,6 +1301,7 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
                 gv = fmaf(h, dv[b], gv);
                 const float dh = h > 0.f ? d : 0.f;
                 L.dhf[(size_t)b * L.FC + jj] = dh;
+                dmax = fmaxf(dmax, fabsf(dh));
                 gb += dh;
             }
         }
@@ -1268,7 +1309,9 @@ __device__ __forceinline__ void loss_head_body(const LossArgs &L, float (*dadv)[
 #pragma unroll
     for (int a = 0; a < AT; a++) part[bg][jl][a] = gw[a];
     part[bg][jl][MAXA] = gv; part[bg][jl][MAXA + 1] = gb;
+    wg_max_write(dmax, wmax, tid >> 6, tid & 63);
     __syncthreads();
+    if (tid == 0) L.gmax[blockIdx.x] = wg_max_read<4>(wmax);
     if (bg == 0) {
         auto total = [&](int c) {
             float v = part[0][jl][c];
@@ -1289,8 +1332,9 @@ __global__ __launch_bounds__(256) void loss_head_kernel(LossArgs L) {
     __shared__ float dv[MAXTB];
     __shared__ float lterm[MAXTB];
     __shared__ float part[16][16][MAXA + 2];
-    if (L.A == 2) loss_head_body<2>(L, dadv, dv, lterm, part);
-    else loss_head_body<MAXA>(L, dadv, dv, lterm, part);
+    __shared__ float wmax[4];
+    if (L.A == 2) loss_head_body<2>(L, dadv, dv, lterm, part, wmax);
+    else loss_head_body<MAXA>(L, dadv, dv, lterm, part, wmax);
 }
 
 // fb_qnet_apply_adam on gradients that no fb_qnet_train_step ticked for (guarded on the device, so it is safe to launch always)
@@ -1309,7 +1353,9 @@ __global__ void mark_split_kernel(AdamDev *ad, int which) { ad->wver[which] = ad
 // behind fc1 (head_kernel, loss_head_kernel).  Here one workgroup owns a 16 x 16 output tile for all of K (its 8 waves split K
 // and are summed through LDS in wave order), so it can finish what depends on the complete sums: it stores the pre-activation
 // sums (slot 0 of the partial-sum buffer: nks = 1 for head_kernel / the env rider) and the tile's share of the head,
-// qpart[tile][row][a] = sum over its 16 units of relu(sum + bias) * W_q[unit][a] (slot A: the same with W_v, dueling).
+// qpart[row][tile][a] = sum over its 16 units of relu(sum + bias) * W_q[unit][a] (slot A: the same with W_v, dueling) -- row-major: the
+// FC / 16 shares of one Q value are consecutive (fc1_bwd2_kernel's 16 lanes per row read 2 cache lines, not 16: with [tile][row] every
+// workgroup of that launch spent ~2.5 us touching 3 000 lines for 36 KB of shares).
 // fc1_bwd2_kernel adds the FC / 16 shares per row in its prologue: two launches and two round trips fewer per train step.
 // The activation rows go through LDS (each wave stages its own 16 x 200 slice with 16-byte coalesced loads: a fragment-shaped
 // global load would touch 64 cache lines per instruction); the weight columns are read directly (4 rows x 64 B per
@@ -1331,6 +1377,11 @@ __global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
     float bv[50];
 #pragma unroll
     for (int t = 0; t < 50; t++) bv[t] = bcol[(size_t)(FK_ABL == 2 ? 0 : t) * a.FC];
+    // the head's parameters of this lane's unit (the epilogue's shares): requested with everything else, not behind the reduction
+    float hb = s.params[a.off.bf1 + n0 + r], hw[MAXA + 1];
+#pragma unroll
+    for (int c = 0; c < MAXA; c++) hw[c] = s.params[a.off.wq + (n0 + r) * a.A + (c < a.A ? c : 0)];
+    hw[MAXA] = s.params[(a.dueling ? a.off.wv : a.off.bf1) + n0 + r];
     // stage the activation slice: 16 rows x 50 float4; rows past the slice are clamped (computed, never stored)
     float *mine = ast + wave * 16 * FK_ROW;
     float4 st[13];
@@ -1372,15 +1423,18 @@ __global__ __launch_bounds__(512) void fc1_fk_kernel(FkArgs a) {
     const size_t srow = (size_t)s.s_off + (live ? mr : M - 1);
     if (live) a.hf[srow * a.FC + unit] = v;                              // pre-activation sum (bias and relu belong to the consumer)
     if (!a.qpart || FK_ABL == 4) return;
-    const float h = fmaxf(v + s.params[a.off.bf1 + unit], 0.f);
+    const float h = fmaxf(v + hb, 0.f);
     const int qs = a.A + 1;
-    float *qo = a.qpart + ((size_t)blockIdx.y * a.stot + srow) * qs;
-    for (int c = 0; c <= a.A; c++) {                                     // A columns of W_q (+ W_v for the dueling head)
-        if (c == a.A && !a.dueling) break;
-        float x = h * (c < a.A ? s.params[a.off.wq + unit * a.A + c] : s.params[a.off.wv + unit]);
+    float *qo = a.qpart + (srow * (size_t)gridDim.y + blockIdx.y) * qs;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 16);       // over the tile's 16 units, fixed tree
-        if (col == 0 && live) qo[c] = x;
+    for (int c = 0; c <= MAXA; c++) {                                    // A columns of W_q (+ W_v for the dueling head)
+        // (fully unrolled, static indices into hw: a loop the compiler cannot unroll turns hw into an alloca that hipcc parks in LDS)
+        if (c < a.A || (c == a.A && a.dueling)) {                        // wave-uniform; no load inside
+            float x = h * (c == a.A ? hw[MAXA] : hw[c]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 16);   // over the tile's 16 units, fixed tree
+            if (col == 0 && live) qo[c] = x;
+        }
     }
 }
 
@@ -1440,6 +1494,10 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
         for (int q = 0; q < 8; q++) pre_w[q] = *reinterpret_cast<const float4 *>(brun + (4 * q < kh ? 4 * q : 0));
 #pragma unroll
         for (int q = 0; q < 16; q++) pre_a[q] = 0.f;
+        // relu'(h3) of the two output rows this wave finishes (reduce_rows deals rows 2 wave, 2 wave + 1 to wave < 8): requested now, not
+        // behind the reduction at the very end of the longest role of this launch
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const int mr = mt * 32 + drow(2 * (wave & 7) + q, lane); pre_a[q] = L.h3[(size_t)(mr < B ? mr : 0) * 1600 + kt * 32 + (lane & 31)]; }
     } else {
         const int c = tid & 31;
 #pragma unroll
@@ -1471,11 +1529,12 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int tile = j + 16 * u, tc = tile < ntile ? tile : 0;
-            const float *q0 = L.qpart + ((size_t)tc * L.stot + bc) * qs;
+            const float *q0 = L.qpart + ((size_t)bc * ntile + tc) * qs;
+            const size_t rs = (size_t)ntile * qs;                        // one row of shares
 #pragma unroll
             for (int c = 0; c <= AT; c++) {
                 const int cc = c < qs ? c : 0;
-                x0[u][c] = q0[cc]; x1[u][c] = q0[(size_t)B * qs + cc]; x2[u][c] = q0[(size_t)(dbl ? 2 * B : 0) * qs + cc];
+                x0[u][c] = q0[cc]; x1[u][c] = q0[(size_t)B * rs + cc]; x2[u][c] = q0[(size_t)(dbl ? 2 * B : 0) * rs + cc];
             }
         }
         keep(rf); keep(isw); keep(termb); keep(a_b);
@@ -1489,12 +1548,13 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
             q3v[c] = (on ? x2[0][c] : 0.f) + (on1 ? x2[1][c] : 0.f);
         }
         for (int tile = j + 32; tile < ntile; tile += 16) {              // FC > 512 only
-            const float *q0 = L.qpart + ((size_t)tile * L.stot + bc) * qs;
+            const float *q0 = L.qpart + ((size_t)bc * ntile + tile) * qs;
+            const size_t rs = (size_t)ntile * qs;
 #pragma unroll
             for (int c = 0; c <= AT; c++) {
                 const int cc = c < qs ? c : 0;
                 const bool on = c < A || (c == A && L.dueling);
-                const float y0 = q0[cc], y1 = q0[(size_t)B * qs + cc], y2 = q0[(size_t)(dbl ? 2 * B : 0) * qs + cc];
+                const float y0 = q0[cc], y1 = q0[(size_t)B * rs + cc], y2 = q0[(size_t)(dbl ? 2 * B : 0) * rs + cc];
                 qsv[c] += on ? y0 : 0.f; qnv[c] += on ? y1 : 0.f; q3v[c] += on ? y2 : 0.f;
             }
         }
@@ -1644,9 +1704,9 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
                 }
             }
         }
-        reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
+        reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int r, int mr) {
             const size_t o = (size_t)mr * 1600 + kt * 32 + jj;
-            L.dh3[o] = BW_ABL == 4 ? v : (L.h3[o] > 0.f ? v : 0.f);
+            L.dh3[o] = BW_ABL == 4 ? v : (((r & 1) ? pre_a[1] : pre_a[0]) > 0.f ? v : 0.f);
         });
         return;
     }
@@ -1819,13 +1879,14 @@ __device__ __forceinline__ void conv_dw_body(int bx, int zslab, int nz, float *r
 // Side outputs dh2 / dp1 (fp32) feed the weight-gradient tiles of the next launch.
 struct BxArgs { const float *dh3, *h2, *p1; float *dh2, *dp1; const uint4 *w3t, *w2t; };
 
-template <int NS> struct BxLds { static constexpr int NPL = NS == 3 ? 2 : 1, U4 = 2 * NPL * 200 + 16 + 2048; };      // uint4 units
+template <int NS> struct BxLds { static constexpr int NPL = NS == 3 ? 2 : 1, U4 = 2 * NPL * 200 + 16 + 2048 + 4; };      // uint4 units (+ 4: the per-wave maxima of the gradient pre-scale)
 
 template <int NS>
 __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *smem) {
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
     constexpr int C2_P = 200, D2O = NPL * C2_P, ZOFF = 2 * NPL * C2_P, RED = ZOFF + 16;
     float *red = reinterpret_cast<float *>(smem + RED);
+    float *sx = red + 8192;                                              // 8 + 8 words: per-wave maxima of dh3, then of dh2 (pow2_scale)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = lane & 31;
     const bool rowok = j < 25;
     // weight fragments: one wave per fragment, straight from L2, three chunks ahead (see conv23_t_kernel)
@@ -1852,9 +1913,19 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
     const int pixB = ((clsB >> 1) + 2 * qy) * 10 + (clsB & 1) + 2 * qx, ciB = 16 * halfB + 4 * hl;   // conv2^T: channels ciB.. and ciB + 8..
     const float *p1p = a.p1 + ((size_t)b * 100 + (rowok ? pixB : 0)) * 32 + ciB;
     const float4 m1a = reinterpret_cast<const float4 *>(p1p)[0], m1b = reinterpret_cast<const float4 *>(p1p)[2];
+    // The sample's gradients are tiny (1e-6 .. 1e-8 with a mean loss): the two-plane fp16 operands get an exact power-of-two pre-scale
+    // from the sample's own maximum |dh3| (S3) and, further down, |dh2| (S2); 1 / S is folded back where a sum leaves the matrix
+    // instruction (pow2_scale).  bf16 (NS = 1) has fp32's exponent range and needs none.
+    Pow2 S3 = {1.f, 1.f}, S2 = {1.f, 1.f};
     {   // dh3 of the sample -> planes [25 pixels][8 pieces of 8 channels], piece q on q ^ ((pix >> 1) & 7)
         const int i = tid < 400 ? tid : 0, pix = i >> 4, q16 = i & 15;
-        const float4 t = reinterpret_cast<const float4 *>(a.dh3 + (size_t)b * 1600)[i];
+        float4 t = reinterpret_cast<const float4 *>(a.dh3 + (size_t)b * 1600)[i];
+        if constexpr (NS == 3) {
+            wg_max_write(fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))), sx, wave, lane);
+            __syncthreads();
+            S3 = pow2_scale(wg_max_read<8>(sx));
+            t.x *= S3.s; t.y *= S3.s; t.z *= S3.s; t.w *= S3.s;
+        }
         uint32_t h0, l0, h1, l1, m_;
         if constexpr (NS == 3) { split2x2(t.x, t.y, h0, l0); split2x2(t.z, t.w, h1, l1); }
         else { split3x2(t.x, t.y, h0, m_, l0); split3x2(t.z, t.w, h1, m_, l1); }
@@ -1913,8 +1984,16 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
                 for (int k = 1; k < 4; k++) v[e] += red[((k * 2 + ctA) * 16 + 4 * qA + e) * 64 + lane];
             }
             v[0] = m2.x > 0.f ? v[0] : 0.f; v[1] = m2.y > 0.f ? v[1] : 0.f; v[2] = m2.z > 0.f ? v[2] : 0.f; v[3] = m2.w > 0.f ? v[3] : 0.f;
+            if constexpr (NS == 3) {
+                // v = S3 * dh2.  Its planes get their own scale from the sample's maximum (the lanes of rows >= 25 hold sums over the
+                // zero page: 0); what goes to memory is the true value
+                wg_max_write(rowok ? fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) : 0.f, sx + 8, wave, lane);
+                __syncthreads();
+                S2 = pow2_scale(wg_max_read<8>(sx + 8));
+            }
             if (rowok) {
-                *reinterpret_cast<float4 *>(a.dh2 + ((size_t)b * 25 + j) * 64 + chA) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(a.dh2 + ((size_t)b * 25 + j) * 64 + chA) = make_float4(v[0] * S3.inv, v[1] * S3.inv, v[2] * S3.inv, v[3] * S3.inv);
+                if constexpr (NS == 3) { v[0] *= S2.s; v[1] *= S2.s; v[2] *= S2.s; v[3] *= S2.s; }
                 uint32_t h0, l0, h1, l1, m_;
                 if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
                 else { split3x2(v[0], v[1], h0, m_, l0); split3x2(v[2], v[3], h1, m_, l1); }
@@ -1929,7 +2008,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
     park((wave >> 2) * 4 + (wave & 3));
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = red[((0 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane] + red[((1 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane];
+    for (int e = 0; e < 8; e++) v[e] = (red[((0 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane] + red[((1 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane]) * S2.inv * S3.inv;
     if (rowok) {
         float *o = a.dp1 + ((size_t)b * 100 + pixB) * 32 + ciB;
         reinterpret_cast<float4 *>(o)[0] = make_float4(m1a.x > 0.f ? v[0] : 0.f, m1a.y > 0.f ? v[1] : 0.f, m1a.z > 0.f ? v[2] : 0.f, m1a.w > 0.f ? v[3] : 0.f);
@@ -1946,9 +2025,13 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
 //   weight gradient  dW[i][n]  = sum_b h3[b][i] * dhf[b][n]: the reduction runs over samples, a lane gathers its 8 k-values with 8
 //                    loads (each one coalesced across the 32 lanes of a half)
 struct FragF { float4 a0, a1, b0, b1; };                // one k-step of one lane: 8 values of each operand
-template <int NS>
-__device__ __forceinline__ void mma_frag(const FragF f, f32x16 &acc, f32x16 &acl) {
+__device__ __forceinline__ float4 mul4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+// GA: which operand is the gradient (dhf) -- it is multiplied by the power of two `gs` before the split (pow2_scale), the caller folds
+// 1 / gs back
+template <int NS, bool GA>
+__device__ __forceinline__ void mma_frag(FragF f, f32x16 &acc, f32x16 &acl, float gs) {
     if constexpr (NS == 3) {
+        if constexpr (GA) { f.a0 = mul4(f.a0, gs); f.a1 = mul4(f.a1, gs); } else { f.b0 = mul4(f.b0, gs); f.b1 = mul4(f.b1, gs); }
         uint4 ah, al, bh, bl;
         split2x2(f.a0.x, f.a0.y, ah.x, al.x); split2x2(f.a0.z, f.a0.w, ah.y, al.y); split2x2(f.a1.x, f.a1.y, ah.z, al.z); split2x2(f.a1.z, f.a1.w, ah.w, al.w);
         split2x2(f.b0.x, f.b0.y, bh.x, bl.x); split2x2(f.b0.z, f.b0.w, bh.y, bl.y); split2x2(f.b1.x, f.b1.y, bh.z, bl.z); split2x2(f.b1.z, f.b1.w, bh.w, bl.w);
@@ -1970,11 +2053,22 @@ __device__ __forceinline__ void mma_frag(const FragF f, f32x16 &acc, f32x16 &acl
 template <int NS, int KX, int KW>
 __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
                                                           const float *__restrict__ dhf, float *__restrict__ dh3,
-                                                          float *__restrict__ grad, int B, int FC) {
+                                                          float *__restrict__ grad, int B, int FC, const float *__restrict__ gmax) {
     __shared__ float red[8 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, r = lane & 31;
     const int tile = blockIdx.x;
     f32x16 acc = {0}, acl = {0};
+    // pre-scale of the gradient operand: the maximum |dhf| of the whole matrix, from the loss kernel's per-workgroup maxima (FC / 16 <= 256
+    // words: four per lane); requested here, consumed behind the fragment loads
+    float gm = 0.f;
+    {
+        const int nm = FC >> 4;
+        float g4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) g4[q] = gmax[lane + 64 * q < nm ? lane + 64 * q : 0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) gm = fmaxf(gm, g4[q]);
+    }
     if (tile < n_dx) {
         const int mt = tile / 50, it = tile - mt * 50, m = mt * 32 + r;
         const int per = KX ? KX : FC / 128, k0 = wave * per;
@@ -1985,14 +2079,20 @@ __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float 
             FragF f[KX];
 #pragma unroll
             for (int q = 0; q < KX; q++) f[q] = ld(q);
+            const Pow2 G = pow2_scale(wave_max(gm));
 #pragma unroll
-            for (int q = 0; q < KX; q++) mma_frag<NS>(f[q], acc, acl);
+            for (int q = 0; q < KX; q++) mma_frag<NS, true>(f[q], acc, acl, G.s);
+            if constexpr (NS == 3) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
+            }
         } else {
-            for (int q = 0; q < per; q++) mma_frag<NS>(ld(q), acc, acl);
-        }
-        if constexpr (NS == 3) {
+            const Pow2 G = pow2_scale(wave_max(gm));
+            for (int q = 0; q < per; q++) mma_frag<NS, true>(ld(q), acc, acl, G.s);
+            if constexpr (NS == 3) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+                for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
+            }
         }
         reduce_rows<8>(acc, red, wave, lane, mt * 32, B, [&](float v, int, int mr) {
             const size_t o = (size_t)mr * 1600 + it * 32 + r;
@@ -2017,18 +2117,19 @@ __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float 
         return FragF{make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]), make_float4(bb[0], bb[1], bb[2], bb[3]),
                      make_float4(bb[4], bb[5], bb[6], bb[7])};
     };
+    const Pow2 G = pow2_scale(wave_max(gm));
     if constexpr (KW > 0) {
         FragF f[KW];
 #pragma unroll
         for (int q = 0; q < KW; q++) f[q] = ld(q);
 #pragma unroll
-        for (int q = 0; q < KW; q++) mma_frag<NS>(f[q], acc, acl);
+        for (int q = 0; q < KW; q++) mma_frag<NS, false>(f[q], acc, acl, G.s);
     } else {
-        for (int q = 0; q < per; q++) mma_frag<NS>(ld(q), acc, acl);
+        for (int q = 0; q < per; q++) mma_frag<NS, false>(ld(q), acc, acl, G.s);
     }
     if constexpr (NS == 3) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+        for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
     }
     reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
         grad[OFF_WF1 + (size_t)(it * 32 + row32) * FC + nt * 32 + r] = v;
@@ -2076,7 +2177,7 @@ constexpr int DW1_IMG_W = 104, DW1_IMG_H = 84, DW1_IMG = DW1_IMG_H * DW1_IMG_W *
 constexpr int DW1_STEPS = 30;
 
 // NSP workgroups per sample (each takes 30 / NSP consecutive steps and writes its own slab: small batches want more than B workgroups)
-template <int NSP> struct Dw1Lds { static constexpr int U4 = DW1_IMG / 16 + (DW1_STEPS / NSP) * 2 * 64 + 64; };      // uint4 units
+template <int NSP> struct Dw1Lds { static constexpr int U4 = DW1_IMG / 16 + (DW1_STEPS / NSP) * 2 * 64 + 64 + 4; };      // uint4 units (+ 4: per-wave maxima of the gradient pre-scale)
 
 // RING: the sample's image comes out of the replay's 1-bit frames (four frame offsets per sample in ring_fo, left by the trunk kernel)
 struct Dw1Ring { const unsigned long long *bits, *fo; };
@@ -2087,6 +2188,7 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
     constexpr int SW = DW1_STEPS / NSP, PU = (SW + 7) / 8;       // steps of this workgroup; fragment-building rounds per wave
     uint4 *img4 = pool, *bfr = pool + DW1_IMG / 16;
     float (*bsum)[32] = reinterpret_cast<float (*)[32]>(bfr + SW * 2 * 64);
+    float *sx = reinterpret_cast<float *>(bfr + SW * 2 * 64 + 64);      // per-wave maxima of |dY| (pow2_scale)
     const int b = blk / NSP, part = blk - b * NSP, s0 = part * SW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, c = lane & 31;
     uint8_t *img = reinterpret_cast<uint8_t *>(img4);
@@ -2104,6 +2206,15 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
             const uint32_t po = ((uint32_t)b * 100u + (uint32_t)(ok ? (oy >> 1) * 10 + px : 0)) * 32u + (uint32_t)c;
             dv[u][q] = dp1[po]; am[u][q] = amax[po];
         }
+    }
+    {   // dY is a gradient (1e-7 .. 1e-9 in the reference's regime): its fp16 planes are built from S1 * dY, S1 a power of two from this
+        // workgroup's maximum |dY| (pow2_scale); the maxima meet through LDS behind the barrier that follows the image's zeroing
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < PU; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) m = fmaxf(m, wave + 8 * u < SW ? fabsf(dv[u][q]) : 0.f);
+        wg_max_write(m, sx, wave, lane);
     }
     // ---- the padded image: zero everything, then the 80 rows of 320 bytes
     // (named registers, not an array: hipcc parked a 4-entry uint4 array in scratch memory here)
@@ -2131,6 +2242,7 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
         };
         put(tid, pxa); put(tid + 512, pxb); put(tid + 1024, pxc); put(tid + 1536, pxd);
     }
+    const Pow2 S1 = pow2_scale(wg_max_read<8>(sx));
     float bs = 0.f;
 #pragma unroll
     for (int u = 0; u < PU; u++) {
@@ -2144,7 +2256,8 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
             v[2 * q + 1] = ok && am[u][q] == pos + 1 ? dv[u][q] : 0.f;
         }
         uint4 fh, fl;
-        split2x2(v[0], v[1], fh.x, fl.x); split2x2(v[2], v[3], fh.y, fl.y); split2x2(v[4], v[5], fh.z, fl.z); split2x2(v[6], v[7], fh.w, fl.w);
+        split2x2(v[0] * S1.s, v[1] * S1.s, fh.x, fl.x); split2x2(v[2] * S1.s, v[3] * S1.s, fh.y, fl.y);
+        split2x2(v[4] * S1.s, v[5] * S1.s, fh.z, fl.z); split2x2(v[6] * S1.s, v[7] * S1.s, fh.w, fl.w);
         if (ls < SW) { bfr[(ls * 2 + 0) * 64 + lane] = fh; bfr[(ls * 2 + 1) * 64 + lane] = fl; }
 #pragma unroll
         for (int q = 0; q < 8; q++) bs += v[q];
@@ -2186,7 +2299,7 @@ __device__ __forceinline__ void conv1_dw2_body(int blk, const uint8_t *__restric
     }
     float *o = slabs + (size_t)blk * slab_stride;
 #pragma unroll
-    for (int r = 0; r < 16; r++) o[OFF_W1 + (ky * 32 + drow(r, lane)) * 32 + c] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]);
+    for (int r = 0; r < 16; r++) o[OFF_W1 + (ky * 32 + drow(r, lane)) * 32 + c] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]) * S1.inv;
     if (wave == 0 && hl == 0) {
         float sum = bsum[0][c];
 #pragma unroll
@@ -2222,11 +2335,13 @@ __global__ __launch_bounds__(512) void conv_bx_kernel(BxArgs bx, int B, int nz, 
     adam_span_body(t - 38 * nz, n_adam, span);
 }
 
+// (the SECOND part of W_fc1's Adam span rides here as n_adam trailing workgroups: the 22.9 MB of the whole span made conv_bx_kernel
+// HBM-bound -- 11 us in the loop against ~8 for its conv chain -- while this launch is latency-bound with ~190 idle CUs as well)
 template <int NSP, bool RING>
 __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const float *__restrict__ p1, const float *__restrict__ dh2,
                                                         const uint8_t *__restrict__ states, const float *__restrict__ dp1,
                                                         const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride,
-                                                        float *__restrict__ slabs1, size_t stride1, int rb, Dw1Ring ring) {
+                                                        float *__restrict__ slabs1, size_t stride1, int rb, Dw1Ring ring, int n_adam, AdamSpan span) {
     const int n2 = 34 * nz;                       // (slabs1 / stride1: where conv1's slabs go -- the common slab set, or the fold buffer)
     __shared__ uint4 pool[Dw1Lds<NSP>::U4];
     static_assert(Dw1Lds<NSP>::U4 >= 2048, "the conv2 tiles borrow the pool");
@@ -2235,7 +2350,8 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
         conv_dw_body<2>(blockIdx.x % 34, blockIdx.x / 34, nz, red, B, p1, dh2, slabs, slab_stride, rb);
         return;
     }
-    conv1_dw2_body<NSP, RING>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool, ring);
+    if ((int)blockIdx.x < n2 + NSP * B) { conv1_dw2_body<NSP, RING>((int)blockIdx.x - n2, states, dp1, amax, slabs1, stride1, pool, ring); return; }
+    adam_span_body((int)blockIdx.x - n2 - NSP * B, n_adam, span);
 }
 
 // ---- conv3 / conv2 weight gradients of a LARGE batch (B a multiple of 16): one workgroup per group of 16 samples and 32 x 32 tile of
@@ -2248,7 +2364,7 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
 // two corner taps 0 and 8), conv2 the 4 taps that meet its parity class x 2 halves of the pixels.  One slab per sample group.
 template <int NS> struct DwgLds {
     static constexpr int NPL = NS == 3 ? 2 : 1, PLH = 25 * 32 * 16;             // halves per plane of one operand
-    static constexpr int U4 = 2 * NPL * PLH / 8 + 64 + 128 + 2048;               // + a zero page (1 KB) + bias partials (512 floats) + the reduction area (8 x 16 x 64 floats)
+    static constexpr int U4 = 2 * NPL * PLH / 8 + 64 + 128 + 2048 + 4;           // + a zero page (1 KB) + bias partials (512 floats) + the reduction area (8 x 16 x 64 floats) + per-wave maxima (pre-scale)
 };
 
 // LAYER 3: blk = (group, ci tile, co tile); LAYER 2: blk = (group, parity class, co tile)
@@ -2259,6 +2375,7 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
     uint16_t *X = reinterpret_cast<uint16_t *>(pool), *DY = X + NPL * PLH;
     float *part = reinterpret_cast<float *>(pool + 2 * NPL * PLH / 8 + 64);
     float *red = part + 512;
+    float *sx = red + 8192;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
     const int cot = blk & 1, mid = LAYER == 3 ? (blk >> 1) & 1 : (blk >> 1) & 3, g = LAYER == 3 ? blk >> 2 : blk >> 3;
     const int py = mid >> 1, px = mid & 1;                                   // (LAYER 2: the parity class)
@@ -2279,6 +2396,17 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
         ya[q] = dy[yo]; yb[q] = dy[yo + 1600];
     }
     if (tid < 64) pool[2 * NPL * PLH / 8 + tid] = make_uint4(0u, 0u, 0u, 0u);
+    // dY is a gradient: its two fp16 planes are built from SY * dY, SY a power of two from the maximum |dY| of this workgroup's operand
+    // block (16 samples x 25 pixels x 32 channels), folded back in fold() (pow2_scale); x is an activation and needs none
+    Pow2 SY = {1.f, 1.f};
+    if constexpr (NS == 3) {
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 13; q++) m = fmaxf(m, wave + 8 * q < 100 ? fmaxf(fabsf(ya[q]), fabsf(yb[q])) : 0.f);
+        wg_max_write(m, sx, wave, lane);
+        __syncthreads();
+        SY = pow2_scale(wg_max_read<8>(sx));
+    }
     float bs = 0.f;
 #pragma unroll
     for (int q = 0; q < 13; q++) {
@@ -2286,7 +2414,7 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
         if (w < 100) {
             const int o = (pos * 32 + r) * 16 + 2 * bp;
             uint32_t h0, l0, h1, l1, m_;
-            if constexpr (NS == 3) { split2x2(xa[q], xb[q], h0, l0); split2x2(ya[q], yb[q], h1, l1); }
+            if constexpr (NS == 3) { split2x2(xa[q], xb[q], h0, l0); split2x2(ya[q] * SY.s, yb[q] * SY.s, h1, l1); }
             else { split3x2(xa[q], xb[q], h0, m_, l0); split3x2(ya[q], yb[q], h1, m_, l1); }
             *reinterpret_cast<uint32_t *>(X + o) = h0; *reinterpret_cast<uint32_t *>(DY + o) = h1;
             if (NS == 3) { *reinterpret_cast<uint32_t *>(X + PLH + o) = l0; *reinterpret_cast<uint32_t *>(DY + PLH + o) = l1; }
@@ -2316,7 +2444,7 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
     auto fold = [&]() {
         if constexpr (NS == 3) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]);
+            for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * SY.inv;
         }
     };
     if constexpr (LAYER == 3) {
@@ -2459,6 +2587,97 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
 }
 
+// The FUSED step's Adam launch (single GPU: the gradient never leaves the step).  Same arithmetic per element as adam_kernel -- adam4 on
+// the slab sums in slab order / the flat gradient -- dealt out differently, so that the update of W_conv2 / W_conv3 can leave their
+// split planes behind (forward [k / 8][plane][co] and transposed [tap * 8 + co / 8][plane][ci], what wsplit_item builds) the way the
+// update of W_conv1 always has (split_w1): a train step that follows WITHOUT an acting forward in between -- the train-only loop,
+// fb_train_steps -- can then start with the ring-fed conv trunk, which reads those planes and has no launch in front of it that could
+// refresh them.  W_fc1's planes stay stale (wver): only the >= 256-state forward reads them, and its conv1 launch re-splits on sight.
+//   workgroups [0, 32)      W_conv2, one tile of 16 k-rows x 64 co each (1024 weights): update, park the new values in LDS, emit the
+//                           2 x 64 forward entries and the 16 x 8 transposed entries (8 weights each, three planes)
+//   workgroups [32, 68)     W_conv3 likewise (36 tiles)
+//   then n_rest             everything else but W_fc1 (the AdamSpan riding in the conv3 backward launch has updated it): W_conv1 +
+//                           b_conv1 (slab sums; W_conv1's planes via split_w1), b_conv2, b_conv3, b_fc1 and the head
+//   then                    fb_train_steps' gather rider, if any
+constexpr int ADAMF_T2 = 32, ADAMF_T3 = 36;
+struct AdamFused {
+    float *p, *m, *v; const float *g; long long n; AdamDev *ad;
+    const float *slabs; size_t slab_stride; int z1, z2, z3;
+    uint16_t *w1s; uint4 *wsp; int FC;
+    int tail0;                       // first float4 behind W_fc1
+    int n_rest;                      // workgroups of the third role
+};
+__global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRider gr) {
+    __shared__ float tile[16][68];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    const int n_adam = ADAMF_T2 + ADAMF_T3 + a.n_rest;
+    if (bid >= n_adam) {
+        gather_body<false>(gr.c, gr.steps, gr.B, gr.idx, (uint4 *)gr.s, (uint4 *)gr.s2, gr.a, gr.r, gr.t, (long long)(bid - n_adam) * 256 + tid);
+        return;
+    }
+    const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
+    auto update = [&](long long q, int z) {          // float4 q of the flat vector; z > 0: its gradient is the sum of z slabs, in slab order
+        float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
+        float4 Gv;
+        if (z > 0) {
+            Gv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int s = 0; s < z; s++) {
+                const float4 t = *reinterpret_cast<const float4 *>(a.slabs + s * a.slab_stride + q * 4);
+                Gv.x += t.x; Gv.y += t.y; Gv.z += t.z; Gv.w += t.w;
+            }
+        } else Gv = reinterpret_cast<const float4 *>(a.g)[q];
+        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
+        reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
+        return P;
+    };
+    if (bid < ADAMF_T2 + ADAMF_T3) {
+        const bool l3 = bid >= ADAMF_T2;
+        const int k0 = 16 * (l3 ? bid - ADAMF_T2 : bid), woff = l3 ? OFF_W3 : OFF_W2, CI = l3 ? 64 : 32;
+        const int kr = tid >> 4, c4 = tid & 15;
+        const float4 P = update((woff + (k0 + kr) * 64 + 4 * c4) >> 2, l3 ? a.z3 : a.z2);
+        *reinterpret_cast<float4 *>(&tile[kr][4 * c4]) = P;
+        __syncthreads();
+        if (tid < 128) {                                                 // forward planes: entry (k8, col) = weights W[8 k8 .. 8 k8 + 7][col]
+            const int k8l = tid >> 6, col = tid & 63;
+            uint4 *o = a.wsp + (l3 ? WSP_W3 : WSP_W2) + (size_t)(k0 / 8 + k8l) * 3 * 64 + col;
+            const float (*t)[68] = &tile[8 * k8l];
+            wsplit_store(o, 64, t[0][col], t[1][col], t[2][col], t[3][col], t[4][col], t[5][col], t[6][col], t[7][col]);
+        } else {                                                         // transposed planes: entry (tap * 8 + co / 8, ci) = 8 consecutive co of row (tap, ci)
+            const int r = (tid - 128) >> 3, co8 = tid & 7, tap = k0 / CI, ci = k0 - tap * CI + r;
+            uint4 *o = a.wsp + (l3 ? wsp_w3t(a.FC) : wsp_w2t(a.FC)) + (size_t)(tap * 8 + co8) * 3 * CI + ci;
+            const float *t = &tile[r][8 * co8];
+            wsplit_store(o, CI, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+        }
+        return;
+    }
+    // the rest, as consecutive float4 ranges of the flat vector: [0, OFF_W2) [OFF_B2, OFF_W3) [OFF_B3, OFF_WF1) [tail0 * 4, n)
+    const int n0 = OFF_W2 / 4, n1 = (OFF_W3 - OFF_B2) / 4, n2 = (OFF_WF1 - OFF_B3) / 4;
+    const long long n4 = a.n >> 2, nq = n0 + n1 + n2 + (n4 - a.tail0);
+    for (long long qq = (long long)(bid - ADAMF_T2 - ADAMF_T3) * 256 + tid; qq < nq; qq += (long long)a.n_rest * 256) {
+        long long q; int z;
+        if (qq < n0) { q = qq; z = a.z1; }
+        else if (qq < n0 + n1) { q = OFF_B2 / 4 + (qq - n0); z = a.z2; }
+        else if (qq < n0 + n1 + n2) { q = OFF_B3 / 4 + (qq - n0 - n1); z = a.z3; }
+        else { q = a.tail0 + (qq - n0 - n1 - n2); z = 0; }
+        const float4 P = update(q, z);
+        if (q * 4 < OFF_B1) {                                            // W_conv1 changed: refresh its two fp16 planes
+            const int idx = (int)q * 4;
+            split_w1(P.x, idx, a.w1s); split_w1(P.y, idx + 1, a.w1s); split_w1(P.z, idx + 2, a.w1s); split_w1(P.w, idx + 3, a.w1s);
+        }
+    }
+    // the update consumes the pending tick and makes a new parameter version, of which the conv planes are current (nothing in this
+    // launch reads these words)
+    if (bid == ADAMF_T2 + ADAMF_T3 && tid == 0) { a.ad->applies = a.ad->ticks; a.ad->pver[0] += 1; a.ad->wverc[0] = a.ad->pver[0]; }
+    if (bid == ADAMF_T2 + ADAMF_T3 && tid < (int)(a.n & 3)) {
+        const long long q = (n4 << 2) + tid;
+        float mm = a.m[q], vv = a.v[q];
+        mm += (a.g[q] - mm) * omb1; vv += (a.g[q] * a.g[q] - vv) * omb2;
+        a.p[q] -= (mm * alpha) / (sqrtf(vv) + eps);
+        a.m[q] = mm; a.v[q] = vv;
+    }
+}
+
 // tf.truncated_normal(stddev=0.01) weights, 0.01 biases (BrainDQN.py:123-152)
 __global__ void init_params_kernel(float *__restrict__ p, long long n, NetOff off, int FC, int A, int dueling,
                                    uint32_t seed_lo, uint32_t seed_hi) {
@@ -2500,11 +2719,13 @@ struct fb_qnet {
     AdamDev *adam;
     // workspace for 3 * max_batch samples
     float *p1, *h2, *h3, *hf, *q;
-    float *qpart;                    // small-batch training: per 16-unit tile shares of the head, [FC/16][S][A + 1]
+    float *qpart;                    // small-batch training: per 16-unit tile shares of the head, [S][FC/16][A + 1]
     unsigned long long *ring_fo;     // ring-fed training: the four frame offsets of every sample's state s, [max_batch][4]
     hipEvent_t grad_ev;              // fb_qnet_set_grad_event: recorded behind the fc1 backward launch of a gradient-exporting step, or NULL
+    hipEvent_t grad_ev_recorded;     // the event the last gradient-exporting step did record (fb_qnet_take_grad_event_recorded)
     uint8_t *amax;
     float *dhf, *dh3, *dh2, *dp1;
+    float *gmax;                     // large batches: the loss kernel's per-workgroup maxima of |dhf| (gradient pre-scale of fc1_bwd_big_kernel), [FC / 16]
     int zmax;
 };
 
@@ -2551,6 +2772,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     const size_t Bm = max_batch;
     alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
     alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
+    alloc((void **)&h->gmax, (size_t)(fc_width / 16) * 4);
     if (e != hipSuccess) {
         fb_set_error(e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP, "fb_qnet_create: %s", hipGetErrorString(e));
         fb_qnet_destroy(h);
@@ -2568,7 +2790,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
     void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->slabs1, h->adam, h->p1, h->amax, h->h2,
-                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1, h->ring_fo};
+                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1, h->ring_fo, h->gmax};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return FB_OK;
@@ -2805,7 +3027,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             LossArgs L;
             L.algo = p.algo; L.B = B; L.FC = FC; L.A = h->A; L.dueling = h->arch == FB_ARCH_DUELING; L.off = h->off;
             L.params = h->params[0]; L.q = h->q; L.hf = h->hf; L.stot = stot; L.nks = FC1_SP_KS; L.act = p.a; L.rew = p.r; L.term = p.t; L.isw = p.isw;      // (only large batches come here: fc1_sp_kernel's 4 K slices)
-            L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
+            L.gamma = p.gamma; L.grad = G; L.dhf = h->dhf; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y; L.gmax = h->gmax;
             // data-parallel path: the loss kernel advances the Adam step counter as well (once per fb_qnet_apply_adam), so the
             // apply needs no launch of its own for it
             // (at most one tick per Adam update: guarded on the device by AdamDev::ticks / applies)
@@ -2833,19 +3055,28 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             const dim3 gb(ntile);
             const bool std_shape = FC == 512 && B == 256;      // the shapes this path sees (MAXTB = 256): fully unrolled instantiation
             if (h->nsplit_train == 3) {
-                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
-                else hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
             } else {
-                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
-                else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC);
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
             }
         }
         // data-parallel path: from here on G[CONV_PARAMS ..) -- W_fc1, b_fc1, the head: 91 % of the bytes -- is final; the caller's side
         // stream can start reducing it while the conv backward below still runs (fb_qnet_set_grad_event)
-        if (!p.apply_adam && h->grad_ev && only < 0) FB_CHECK_HIP(hipEventRecord(h->grad_ev, st));
+        if (!p.apply_adam && only < 0) {
+            h->grad_ev_recorded = nullptr;
+            if (h->grad_ev) { FB_CHECK_HIP(hipEventRecord(h->grad_ev, st)); h->grad_ev_recorded = h->grad_ev; }
+        }
         // fused single-GPU update: W_fc1's Adam rides in this launch (AdamSpan); the data-parallel path exports the gradient instead
         const int span0 = OFF_WF1 / 4, span1 = p.apply_adam ? (OFF_WF1 + 1600 * FC) / 4 : span0;
-        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
+        // ... in two parts: [span0, spanm) beside the conv data-gradient chain, [spanm, span1) beside the conv weight gradients
+        // (measured, profiles/r03_notes.md: any split costs the same ~3.5 us in all -- the span is HBM traffic at ~6.5 TB/s and what it slows
+        // is the latency-bound chains beside it, wherever it rides -- so the default stays "all of it beside the data-gradient chain")
+        static const int span_pct = getenv("FB_SPAN_SPLIT") ? atoi(getenv("FB_SPAN_SPLIT")) : 100;     // tuning knob: per cent of the span in the first launch
+        const int spanm = span0 + (int)(((long long)(span1 - span0) * span_pct / 100) & ~511LL);
+        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, spanm};
+        const AdamSpan span_b{h->params[0], h->adam_m, h->adam_v, G, h->adam, spanm, span1};
         FbSampleRider srider;
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
@@ -2856,7 +3087,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             const bool fold1 = 2 * B > h->zmax;
             const int fold = (2 * B + h->zmax - 1) / h->zmax;
             z1 = fold1 ? (2 * B + fold - 1) / fold : 2 * B;
-            const int n_adam5 = (span1 - span0 + 511) / 512;
+            static const int span_cap = getenv("FB_SPAN_BLOCKS") ? atoi(getenv("FB_SPAN_BLOCKS")) : 1 << 30;      // tuning knob: at most this many span workgroups per launch (grid-stride)
+            const int n_adam5 = min(span_cap, (spanm - span0 + 511) / 512), n_adam5b = min(span_cap, (span1 - spanm + 511) / 512);
             const BxArgs bx{h->dh3, h->h2, h->p1, h->dh2, h->dp1, h->wsp[0] + wsp_w3t(FC), h->wsp[0] + wsp_w2t(FC)};
             // large batches (multiples of 16): conv3's and conv2's weight gradients per group of 16 samples in a launch of their own
             // (conv_dwg_kernel) instead of as 38 + 34 tiles per slab inside the two launches below; one slab per group
@@ -2879,8 +3111,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
                 float *s1 = fold1 ? h->slabs1 : h->slabs;
                 const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
-                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * zt2 + 2 * B), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
-                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr);
+                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * zt2 + 2 * B + n_adam5b), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b);
+                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B + n_adam5b), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
             }
         }
@@ -2892,9 +3124,14 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             FbGatherRider gr;
             memset(&gr, 0, sizeof(gr));
             if (p.gather_rider) gr = *p.gather_rider;
-            const int nab = (int)((h->n / 4 - (span1 - span0) + 255) / 256), ngb = (int)(((long long)gr.B * 1600 + 255) / 256);
-            hipLaunchKernelGGL(adam_kernel, dim3(nab + ngb), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, G,
-                               h->n, h->adam, (const float *)h->slabs, ss, z1, z2, z3, h->w1s[0], span0, span1, nab, gr);
+            const int ngb = (int)(((long long)gr.B * 1600 + 255) / 256);
+            AdamFused af;
+            af.p = h->params[0]; af.m = h->adam_m; af.v = h->adam_v; af.g = G; af.n = h->n; af.ad = h->adam;
+            af.slabs = h->slabs; af.slab_stride = ss; af.z1 = z1; af.z2 = z2; af.z3 = z3;
+            af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = FC; af.tail0 = span1;
+            const long long nrest4 = OFF_W2 / 4 + (OFF_W3 - OFF_B2) / 4 + (OFF_WF1 - OFF_B3) / 4 + (h->n / 4 - span1);
+            af.n_rest = (int)((nrest4 + 255) / 256);
+            hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest + ngb), dim3(256), 0, st, af, gr);
         }
     }
 #undef FB_K
@@ -2986,6 +3223,14 @@ extern "C" int fb_qnet_set_grad_event(fb_qnet_t h, void *event) {
     return FB_OK;
 }
 
+void *fb_qnet_get_grad_event(fb_qnet_t h) { return h ? (void *)h->grad_ev : nullptr; }
+void *fb_qnet_take_grad_event_recorded(fb_qnet_t h) {
+    if (!h) return nullptr;
+    void *e = (void *)h->grad_ev_recorded;
+    h->grad_ev_recorded = nullptr;
+    return e;
+}
+
 extern "C" int64_t fb_qnet_grad_split(fb_qnet_t h) { return h ? (int64_t)CONV_PARAMS : 0; }
 
 extern "C" int fb_qnet_sync_target(fb_qnet_t h, void *stream) {
@@ -3023,12 +3268,34 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
 }
 
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, const float *isw, double gamma, float *loss, float *abs_err,
-                            float *flat_grad, void *stream) {
+                            float *flat_grad, void *stream, const FbSampleRider *rider) {
     FB_REQUIRE(h && ring && ring->idx && ring->a && ring->r && ring->t, "fb_qnet_train_step_ring: NULL argument");
     Plan p;
     int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, isw, gamma, loss, abs_err, nullptr, flat_grad, &p, ring);
     if (rc != FB_OK) return rc;
+    p.sample_rider = rider;
     return run_plan(h, p, -1, fb_stream(stream));
+}
+
+// the conv part of both nets' planes alone (W_conv2 / W_conv3, forward + transposed): what the ring-fed conv trunk reads.  Guarded on
+// the device by AdamDev::pver / wverc -- after a fused step (adam_fused_kernel emits these planes) the launch returns at once.
+__global__ void wsplit_conv_both_kernel(const float *__restrict__ p0, const float *__restrict__ p1, uint4 *__restrict__ w0, uint4 *__restrict__ w1, int FC,
+                                        const AdamDev *__restrict__ ad) {
+    const int n = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ad->pver[n] == ad->wverc[n] || q >= 2 * IT_CONV) return;
+    wsplit_item(n ? p1 : p0, n ? w1 : w0, FC, conv_item(q, FC));
+}
+__global__ void mark_conv_split_both_kernel(AdamDev *ad) {
+    const int n = threadIdx.x;
+    if (n < 2) ad->wverc[n] = ad->pver[n];
+}
+int fb_qnet_refresh_conv_planes(fb_qnet_t h, void *stream) {
+    FB_REQUIRE(h, "fb_qnet_refresh_conv_planes: NULL handle");
+    hipLaunchKernelGGL(wsplit_conv_both_kernel, dim3((2 * IT_CONV + 255) / 256, 2), dim3(256), 0, fb_stream(stream), h->params[0], h->params[1], h->wsp[0],
+                       h->wsp[1], h->FC, (const AdamDev *)h->adam);
+    hipLaunchKernelGGL(mark_conv_split_both_kernel, dim3(1), dim3(64), 0, fb_stream(stream), h->adam);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
 }
 
 // both nets in one launch (blockIdx.y = net; every thread checks its net's versions) + one marking launch
@@ -3117,6 +3384,6 @@ extern "C" const char *fb_qnet_kernel_name(int kernel) {
     // conv3 rides in conv23_t_kernel, head / loss in fc1_fk_kernel / fc1_bwd2_kernel, conv1's dW in conv_dw21_kernel
     static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv23_t_kernel", "(conv3: in conv23_t)", "fc1_fk_kernel", "head_kernel",
                                          "(loss: in fc1_bwd2)", "fc1_bwd2_kernel", "conv_bx_kernel", "conv_dw21_kernel",
-                                         "(conv1 dW: in conv_dw21)", "slab_reduce_kernel", "adam_kernel"};
+                                         "(conv1 dW: in conv_dw21)", "slab_reduce_kernel", "adam_fused_kernel"};
     return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }

@@ -110,6 +110,17 @@ class OverlappedAllReduce:
             self.on = False
 
 
+class NativeUnavailable(RuntimeError):
+    """raised by NativeDP() on EVERY rank alike when some rank cannot take the native path: fall back to torch.distributed"""
+
+
+def native_wanted():
+    """The library's own communicator is OPT-IN (FB_DP_NATIVE=1): its multi-rank path (csrc/fb_dist.hip, fb_vec_step_dp) has only ever
+    run at world size 1 -- no multi-GPU node has been available to this build -- so torch.distributed's all-reduce, which has, stays the
+    default until a 2-rank run has compared replicas bit for bit."""
+    return os.environ.get("FB_DP_NATIVE", "0") == "1"
+
+
 class NativeDP:
     """The library's own RCCL communicator (csrc/fb_dist.hip): the data-parallel step's all-reduce issued from the C side, straight onto
     the step's HIP stream, no detour through torch.distributed's RCCL stream (two cross-stream hops per collective); optionally in two
@@ -118,26 +129,57 @@ class NativeDP:
 
     def __init__(self, rank=None, world=None, overlap=None):
         """overlap: False = one all-reduce of the whole gradient on the step's stream (default), True = in two pieces with the large one
-        on a side stream behind the fc1 backward launch (default from FB_DP_OVERLAP=1).  See csrc/fb_dist.hip for when which wins."""
+        on a side stream behind the fc1 backward launch (default from FB_DP_OVERLAP=1).  See csrc/fb_dist.hip for when which wins.
+
+        COLLECTIVE over the ranks of torch.distributed, in three phases, so that no rank can be left waiting in a collective its peers
+        never enter:
+          1. rank-local, fallible, non-collective: every rank loads RCCL (fb_dist_probe), rank 0 also draws the unique id;
+          2. agreement: all_reduce(MIN) of "phase 1 worked here" -- if any rank failed, EVERY rank raises NativeUnavailable here (the
+             caller falls back to torch.distributed's all-reduce, all ranks alike); nothing of RCCL's own has been exchanged yet;
+          3. the id is broadcast and every rank enters ncclCommInitRank (fb_dist_create).  From the broadcast on a failure is FATAL
+             (FbError): a rank that fell back now would leave its peers blocked inside ncclCommInitRank."""
         from . import _lib as L
+        self.handle = None
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         lib = L.lib()
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = path.encode() if os.path.exists(path) else None
         uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            L.check(lib.fb_dist_unique_id(path, uid.data_ptr()), "fb_dist_unique_id")
+        # -- 1: what can fail on one rank alone
+        err = None
+        try:
+            L.check(lib.fb_dist_probe(path), "fb_dist_probe")
+            if self.rank == 0:
+                L.check(lib.fb_dist_unique_id(path, uid.data_ptr()), "fb_dist_unique_id")
+        except Exception as e:                               # noqa: BLE001  (any failure here means "not on this rank")
+            err = e
+        on_gpu = self.world > 1 and dist.get_backend() == "nccl"
+        # -- 2: every rank learns whether every rank got this far
+        if not self.agree(err is None, self.world, on_gpu):
+            raise NativeUnavailable(f"rank {self.rank}: " + (f"{type(err).__name__}: {err}" if err else "another rank cannot load RCCL"))
+        # -- 3: collective set-up; no way back from here
         if self.world > 1:
-            on_gpu = dist.get_backend() == "nccl"
             t = uid.cuda() if on_gpu else uid
             dist.broadcast(t, src=0)
             uid = t.cpu()
         self.handle = lib.fb_dist_create(path, self.rank, self.world, uid.data_ptr())
         if not self.handle:
-            raise L.FbError("fb_dist_create: " + lib.fb_last_error().decode("utf-8", "replace"))
+            raise L.FbError("fb_dist_create failed after the unique id was exchanged (fatal: the other ranks are inside "
+                            "ncclCommInitRank): " + lib.fb_last_error().decode("utf-8", "replace"))
         self.overlap = bool(overlap) if overlap is not None else os.environ.get("FB_DP_OVERLAP", "0") == "1"
         L.check(lib.fb_dist_set_overlap(self.handle, int(self.overlap)), "fb_dist_set_overlap")
+
+    @staticmethod
+    def agree(ok_here, world, on_gpu=False):
+        """True when `ok_here` holds on EVERY rank (one all_reduce(MIN); world size 1: ok_here itself)."""
+        if world <= 1 or not dist.is_initialized():
+            return bool(ok_here)
+        t = torch.tensor([1 if ok_here else 0], dtype=torch.int32)
+        if on_gpu:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     def close(self):
         if self.handle:

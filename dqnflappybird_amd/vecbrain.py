@@ -38,23 +38,16 @@ class HipVecBackend:
 
     def native(self, rank, world):
         """the library's own RCCL communicator (dist.NativeDP): with it the whole data-parallel step -- all-reduce and Adam included --
-        is the one host call fb_vec_step_dp.  FB_DP_NATIVE=0 keeps torch.distributed's all-reduce between the step and Adam."""
-        import os
+        is the one host call fb_vec_step_dp.  Opt-in (FB_DP_NATIVE=1, dist.native_wanted); otherwise torch.distributed's all-reduce
+        sits between the step and Adam.  NativeDP() itself makes the ranks agree: it either succeeds on every rank or raises
+        NativeUnavailable on every rank (fallback, all alike); a failure after its id exchange is fatal and propagates."""
         import torch.distributed as tdist
-        if os.environ.get("FB_DP_NATIVE", "1") == "0" or not tdist.is_initialized() or tdist.get_backend() != "nccl":
+        if not fdist.native_wanted() or not tdist.is_initialized() or tdist.get_backend() != "nccl":
             return None
-        import torch
-        native = None
         try:
-            native = fdist.NativeDP(rank, world)
-        except Exception:                                    # no RCCL to load, communicator refused, ...: torch's collective instead
-            native = None
-        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device="cuda")
-        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)          # every rank takes the same path
-        if ok.item() == 0 and native is not None:
-            native.close()
-            native = None
-        return native
+            return fdist.NativeDP(rank, world)
+        except fdist.NativeUnavailable:
+            return None
 
     def zeros(self, n):
         import torch

@@ -40,8 +40,9 @@ const char *fb_last_error(void);
 int fb_version(void);
 /* number of visible HIP devices, or a negative error; used by the shim to fail loudly */
 int fb_device_count(void);
-/* Diagnostics: install a SIGABRT handler that writes the aborting thread's native call stack to stderr before the previous handler
- * runs (the GPU runtimes abort() on fatal errors, not always with a message). */
+/* Diagnostics: install a SIGABRT handler that writes the aborting thread's native call stack to stderr -- and to the file the
+ * environment variable FB_ABORT_LOG names, if set: a test runner may have captured descriptor 2 -- before the previous handler
+ * runs (the GPU runtimes abort() on fatal errors, not always with a message).  Idempotent. */
 int fb_debug_abort_backtrace(void);
 
 /* ------------------------------------------------------------------ environment
@@ -326,6 +327,10 @@ int fb_profile_ring_kernel(fb_replay_t replay, fb_qnet_t net, int kernel, int re
  * broadcasts them, dqnflappybird_amd/dist.py), every rank calls fb_dist_create (collective: ncclCommInitRank) with its HIP device current.
  * librccl_path: the librccl.so the process already holds (a Python host's framework usually bundles one), or NULL for the default search. */
 typedef struct fb_dist *fb_dist_t;
+/* rank-local, non-collective: 0 when this process can load RCCL and resolve its symbols.  Every rank calls it (and rank 0
+ * fb_dist_unique_id) BEFORE the ranks agree to take this path; once the id has been exchanged a failure of fb_dist_create on one
+ * rank leaves its peers inside ncclCommInitRank, so from there on a failure must end the job, not fall back. */
+int fb_dist_probe(const char *librccl_path);
 int fb_dist_unique_id(const char *librccl_path, uint8_t *id128 /*[host] out*/);
 fb_dist_t fb_dist_create(const char *librccl_path, int rank, int world, const uint8_t *id128 /*[host]*/);
 void fb_dist_destroy(fb_dist_t d);

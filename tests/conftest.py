@@ -34,6 +34,9 @@ def _native_stack_on_abort():
     thread first (pytest's faulthandler then adds the interpreter's).  Diagnostics only; never fails a run."""
     try:
         from dqnflappybird_amd import _lib
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):                   # (the GPU box: what is written there comes back with the call)
+            os.environ.setdefault("FB_ABORT_LOG", os.path.join(out, "abort_trace.txt"))
         _lib.lib().fb_debug_abort_backtrace()
     except Exception:
         pass

@@ -147,3 +147,57 @@ def test_single_process_is_a_no_op():
     assert fdist.allreduce_gradients(g, True) is g and torch.equal(g, torch.ones(10))
     with pytest.raises(ValueError):
         fdist.shard_envs(10, 0, 3)
+
+
+# ------------------------------------------------------------------ NativeDP: the failure path of the agreement protocol
+def _native_worker(rank, world, port, fail_rank, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from dqnflappybird_amd import _lib as L
+    from dqnflappybird_amd import dist as fdist
+    fdist.init("gloo")
+    lib = L.lib()                                        # (the shared object loads without a GPU; nothing is launched here)
+    if rank == fail_rank:                                # this rank "cannot load RCCL"
+        class _Lib:                                      # the real library with one entry point failing
+            def __getattr__(self, name):
+                if name == "fb_dist_probe":
+                    return lambda path: -1
+                return getattr(lib, name)
+        L._lib = _Lib()
+    try:
+        fdist.NativeDP(rank, world)
+        outcome = "created"
+    except fdist.NativeUnavailable:
+        outcome = "unavailable"
+    except Exception as e:                               # noqa: BLE001
+        outcome = type(e).__name__
+    # every rank is still in step: a later collective of the job matches up (a rank stuck in / skipped past a broadcast would
+    # deadlock or mismatch here; mp.spawn's join would never return)
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    with open(os.path.join(out_dir, f"o{rank}.txt"), "w") as f:
+        f.write(f"{outcome} {t.item()}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_native_dp_one_rank_failing_makes_every_rank_fall_back(tmp_path, fail_rank):
+    """ADVICE (round 2): NativeDP used to do rank-local fallible work between collectives -- a rank that failed before the id broadcast
+    went on to the agreement all-reduce while its peers sat in the broadcast (mismatched collectives: a hang).  Now: local work first,
+    one all_reduce(MIN), and only then the id exchange; with one rank unable to load RCCL EVERY rank raises NativeUnavailable before
+    anything of RCCL's has been exchanged, and the job's next collective still matches up."""
+    port = 29300 + (os.getpid() % 150) + 200 * fail_rank
+    mp.spawn(_native_worker, args=(2, port, fail_rank, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        outcome, total = (tmp_path / f"o{r}.txt").read_text().split()
+        assert outcome == "unavailable", (r, outcome)
+        assert float(total) == 3.0
+
+
+def test_native_is_opt_in(monkeypatch):
+    from dqnflappybird_amd import dist as fdist
+    monkeypatch.delenv("FB_DP_NATIVE", raising=False)
+    assert not fdist.native_wanted()
+    monkeypatch.setenv("FB_DP_NATIVE", "1")
+    assert fdist.native_wanted()
+    assert fdist.NativeDP.agree(True, 1) and not fdist.NativeDP.agree(False, 1)

@@ -327,3 +327,96 @@ def test_act_epsilon_greedy(torch_cuda, oracle):
     a3 = net.act(sd, epsilon=0.03, seed=1, step=7).cpu().numpy()     # INITIAL_EPSILON
     frac = (a3 != q.argmax(1)).mean()
     assert 0.003 < frac < 0.04                                        # ~ eps/2 of the envs deviate
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's OWN numeric regime: weights as BrainDQN.py:123-152 draws them (truncated normal, sigma = 0.01, biases 0.01 --
+# where a run sits for its first millions of steps at lr 1e-6), the mean losses of BrainDQNNature.py:119 /
+# BrainPrioritizedReplyDQN.py:249-251 (PER: x ISWeights << 1), rewards 0.1 / 3 / -3.  There the conv-layer data gradients are
+# 1e-6 .. 1e-9, far below fp16's normal range: the two-plane fp16 operands of the backward kernels are pre-scaled by exact powers
+# of two (fb_qnet.hip pow2_scale).  The yardstick is what PLAIN fp32 arithmetic achieves on the same problem: the same backward pass
+# in torch-CPU float32 (fp32 products, fp32 accumulation), both measured against the fp64-accumulating oracle, per tensor.
+TENSORS = [("W_conv1", 0, 8192), ("b_conv1", 8192, 8224), ("W_conv2", 8224, 40992), ("b_conv2", 40992, 41056),
+           ("W_conv3", 41056, 77920), ("b_conv3", 77920, 77984), ("W_fc1", 77984, 77984 + 1600 * 512),
+           ("b_fc1", 77984 + 1600 * 512, 77984 + 1600 * 512 + 512), ("head", 77984 + 1600 * 512 + 512, None)]
+FP32_FACTOR = 3.0       # a tensor's error may be at most this many times plain fp32's own error on it (measured: 0.3 .. 1.4; round 2's unscaled planes: up to 64) ...
+FP32_FLOOR = 3e-7       # ... where that error is itself not below a few fp32 roundings (relative L2)
+
+
+def torch_fp32_grads(params, s, dq, dueling):
+    """the backward pass of sum(Q * dq) in plain float32 on the CPU (tests/test_oracle_qnet.py's statement of the graph)"""
+    import torch
+    from tests.test_oracle_qnet import torch_forward
+    torch.set_num_threads(8)
+    pt = torch.tensor(params, dtype=torch.float32, requires_grad=True)
+    q = torch_forward(pt, torch.tensor(s, dtype=torch.float32), dueling=dueling)
+    (q * torch.tensor(dq, dtype=torch.float32)).sum().backward()
+    return pt.grad.numpy()
+
+
+def _regime_report(lines):
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "grad_regime.txt"), "a") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("algo,dueling,B", [("nature", False, 32), ("per", False, 32), ("dqn", False, 32), ("nature", True, 32),
+                                            ("double", False, 256)])
+def test_train_step_gradients_in_the_reference_regime(torch_cuda, oracle, algo, dueling, B):
+    torch = torch_cuda
+    import zlib
+    from dqnflappybird_amd.vec import QNet
+    cfg = oracle.qcfg(512, 2, dueling)
+    p_on, p_tg = oracle.init_params(cfg, seed=1), oracle.init_params(cfg, seed=2)       # UNSCALED: sigma 0.01, biases 0.01
+    net = QNet(2, 512, "dueling" if dueling else "plain", max_batch=B)
+    net.load_params(p_on, 0)
+    net.load_params(p_tg, 1)
+    # kink-free data (see test_train_step_gradients_match_oracle); pre-activations are O(0.01 .. 25) here and the device's differ
+    # from the oracle's by ~1e-7 of that
+    need = 2e-6 if B <= 32 else 3e-7
+    for attempt in range(40 if B <= 32 else 8):
+        rng = np.random.default_rng(zlib.crc32(f"regime-{algo}-{dueling}-{B}-{attempt}".encode()))
+        s, s2 = rand_states(rng, B), rand_states(rng, B)
+        oracle.forward(p_on, cfg, s)
+        if oracle.last_margin() > need:
+            break
+    else:
+        pytest.fail("no kink-free batch found")
+    a = rng.integers(0, 2, B).astype(np.uint8)
+    r = rng.choice(np.array([0.1, 3, -3], np.float32), B, p=[0.8, 0.1, 0.1])
+    t = (r == -3).astype(np.uint8)
+    isw = (0.02 + 0.2 * rng.random(B)).astype(np.float32) if algo == "per" else None       # ISWeights << 1, like early in a run (beta 0.4)
+    d = lambda x: None if x is None else torch.from_numpy(x).cuda()
+    grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda")
+    loss, ae, y = net.train_step(algo, d(s), d(a), d(r), d(s2), d(t), isw=d(isw), flat_grad=grad)
+    y0, loss0, ae0, g0 = oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw)
+    np.testing.assert_allclose(y.cpu().numpy(), y0, rtol=0, atol=Q_ATOL)
+    np.testing.assert_allclose(loss.item(), loss0, rtol=1e-5)
+    # plain fp32 on the same dQ
+    q = oracle.forward(p_on, cfg, s)
+    qn = (oracle.forward(p_on, cfg, s2).max(1) if algo == "dqn" else
+          oracle.forward(p_tg, cfg, s2)[np.arange(B), oracle.forward(p_on, cfg, s2).argmax(1)] if algo == "double" else
+          oracle.forward(p_tg, cfg, s2).max(1))
+    _, _, _, dq = oracle.dqn_loss({"dqn": 0, "nature": 1, "double": 1, "per": 2}[algo], q, qn, a, r, t, isw=isw)
+    g32 = torch_fp32_grads(p_on, s, dq, dueling)
+    g = grad.cpu().numpy()
+    lines = [f"[{algo} dueling={dueling} B={B}]  max|dQ| {np.abs(dq).max():.3e}"]
+    worst = 0.0
+    for name, lo, hi in TENSORS:
+        ref = g0[lo:hi].astype(np.float64)
+        n0 = np.linalg.norm(ref)
+        assert n0 > 0
+        e_dev = np.linalg.norm(g[lo:hi] - ref) / n0
+        e_f32 = np.linalg.norm(g32[lo:hi] - ref) / n0
+        m_dev = np.abs(g[lo:hi] - ref).max() / np.abs(ref).max()
+        lines.append(f"  {name:8s} |g|max {np.abs(ref).max():.2e}  relL2 device {e_dev:.2e}  plain fp32 {e_f32:.2e}  ratio {e_dev / max(e_f32, 1e-30):5.2f}   max-err/max {m_dev:.2e}")
+        worst = max(worst, e_dev / max(e_f32, FP32_FLOOR))
+    _regime_report(lines)
+    for name, lo, hi in TENSORS:
+        ref = g0[lo:hi].astype(np.float64)
+        n0 = np.linalg.norm(ref)
+        e_dev = np.linalg.norm(g[lo:hi] - ref) / n0
+        e_f32 = np.linalg.norm(g32[lo:hi] - ref) / n0
+        assert e_dev <= FP32_FACTOR * max(e_f32, FP32_FLOOR), "\n".join(lines)
