@@ -10,8 +10,9 @@ Workload (BASELINE.json configs[1]): per GPU 1024 vectorised envs + BrainDQN (un
 envs: getAction for 1024 envs from their currentState (forward + epsilon-greedy) -> frame_step (render +
 preprocess fused) -> store -> random.sample(32) -> minibatch gather -> _trainQNetwork (target
 forward, forward, backward, Adam; with N > 1 one RCCL all-reduce of the flat gradient).
-`value` = env-steps/s over all ranks in that loop.  The train-only leg (sample -> gather -> train)
-gives `grad_steps_per_sec`, the env-only leg `env_only_steps_per_sec`.  Everything is device
+`value` = env-steps/s over all ranks in that loop.  The train-only leg (random.sample -> train step fed from the frame ring)
+gives `grad_steps_per_sec` (also inside `config.train_only` and `roofline`, where the driver's record keeps it), the env-only leg
+`env_only_steps_per_sec`.  Everything is device
 resident when the timed region starts; nothing crosses PCIe inside it.
 """
 import argparse
@@ -93,24 +94,16 @@ def main():
     replay.reset(env.frame_bits)
     eps = 0.03                                              # INITIAL_EPSILON (BrainDQN.py:25)
 
-    def train(step):
+    from dqnflappybird_amd.vec import train_from_replay
+
+    def train(step):                                        # the separate calls: random.sample -> train step fed from the ring
         idx, _ = replay.sample(BATCH)
-        s, a, r, s2, t = replay.gather(idx)
         if world > 1:
-            net.train_step("dqn", s, a, r, s2, t, flat_grad=grad, want_aux=False)
+            train_from_replay(replay, net, "dqn", idx, flat_grad=grad)
             dist.all_reduce(grad)                           # sum loss (BrainDQN.py:162) -> plain sum
             net.apply_adam(grad)
         else:
-            net.train_step("dqn", s, a, r, s2, t, want_aux=False)
-
-    def train_on(idx):
-        s, a, r, s2, t = replay.gather(idx)
-        if world > 1:
-            net.train_step("dqn", s, a, r, s2, t, flat_grad=grad, want_aux=False)
-            dist.all_reduce(grad)
-            net.apply_adam(grad)
-        else:
-            net.train_step("dqn", s, a, r, s2, t, want_aux=False)
+            train_from_replay(replay, net, "dqn", idx)
 
     # the whole step as one host call (fb_vec_step: act on the nibble states -> env -> store + random.sample ->
     # train from the ring; the same launches as the separate calls, without the interpreter between them).
@@ -245,24 +238,30 @@ def main():
         pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
 
         def add(name, us, per_step, bound, work, split=0):
-            # split = s > 0: the kernel computes every fp32 product as s fp16 x fp16 MFMA products of two-plane operands
-            # (DESIGN.md section 4): conv1 2 (its u8 input is exact in fp16), the acting conv2/conv3/fc1 kernels 3; priced
-            # against the dense fp16 MFMA peak (= the bf16 one).
+            """bound: what limits the kernel as DESIGN.md section 4 states it -- "mfma" | "hbm" (achieved / peak / frac priced on the
+            ALGORITHMIC flops / bytes of SURVEY 8d) | "lds" | "latency" (dependent chains: the figure of merit is the time per
+            launch; achieved = frac = null, no bandwidth is claimed).
+            split = s > 0: the kernel computes every fp32 product as s fp16 x fp16 MFMA products of two-plane operands (DESIGN.md
+            section 4: conv1 2 -- its u8 input is exact in fp16 --, conv2 / conv3 / fc1 3).  `achieved` / `frac` stay ALGORITHMIC
+            (fp32-equivalent flops / time / dense fp16 MFMA peak); `achieved_issued` / `frac_issued` count the s products the matrix
+            pipe really executes."""
             split = split or (2 if name.startswith("conv1_pool_kernel") else 3 if name.startswith("conv23_t_kernel") else 0)
-            peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF)
-            ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
-            k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound,
-                 "achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-                 "frac": round(ach / peak, 5), "traffic": pmc.get(name)}
-            if split:
-                # the kernel's algorithm IS `split` fp16 products per fp32 product: achieved = the fp16 flops it
-                # performs (all of them necessary), beside the fp32-equivalent rate they amount to
-                k["dtype"] = f"f16x{split} (fp32 result)"
-                k["fp32_equivalent_tflops"] = k["achieved"]
-                k["achieved"] = round(split * ach, 3)
-                k["frac"] = round(split * ach / peak, 5)
-                k["note"] = ("peak = nominal dense fp16/bf16 MFMA; tools/mb/mb_mfma3.hip measures 1.47 PFLOP/s sustained on "
-                             "random operands with all CUs busy (power throttling), 2.3 PFLOP/s on zeros")
+            k = {"kernel": name, "us": round(us, 3), "launches_per_step": per_step, "bound": bound, "traffic": pmc.get(name)}
+            if bound in ("lds", "latency"):
+                k.update({"achieved": None, "peak": None, "unit": "us per launch", "frac": None})
+                if work:
+                    k["algorithmic_GBps"] = round(work / us / 1e3, 1)
+            else:
+                peak = HBM_PEAK_GBS if bound == "hbm" else (MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF)
+                ach = work / us / 1e3 if bound == "hbm" else work / us / 1e6      # GB/s | TFLOP/s
+                k.update({"achieved": round(ach, 3), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 5)})
+                if split:
+                    k["dtype"] = f"f16x{split:g} (fp32 result)"
+                    k["frac_basis"] = "algorithmic: SURVEY 8(d) fp32-equivalent flops / time / dense fp16 MFMA peak"
+                    k["achieved_issued"] = round(split * ach, 3)
+                    k["frac_issued"] = round(split * ach / peak, 5)
+                    k["note"] = (f"the kernel issues {split:.3g} fp16 MFMA products per fp32 MAC (frac_issued); peak = nominal dense fp16/bf16 MFMA; "
+                                 "tools/mb/mb_mfma3.hip measures 1.47 PFLOP/s sustained on random operands with all CUs busy, 2.3 on zeros")
             kernels.append(k)
 
         scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
@@ -278,14 +277,22 @@ def main():
         # acting forward, n = 1024
         scratch.act_nib(nib, 0.0)
         # (>= 256 states, forward only: the two-plane fp16 kernels; conv2 + conv3 in one launch)
-        act = [(0, "conv1_sp_kernel<nib>", FWD_FLOP["conv1_pool_kernel"], 2),
-               (1, "conv23_sp_kernel", FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"], 3),
+        # (>= 256 nibble states: conv1 + conv2 + conv3 in ONE launch, conv1's output handed to conv2 in LDS; then fc1 on K slices)
+        c1f, c23f = FWD_FLOP["conv1_pool_kernel"], FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"]
+        act = [(0, "conv1_sp_kernel<nib>", c1f, 2),                  # (a launch of its own only with FB_ACT_FUSED=0)
+               (1, "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 4 states per workgroup]", c1f + c23f, (2 * c1f + 3 * c23f) / (c1f + c23f)),
                (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 3), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]
         for k, name, flop, split in act:
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
                                                                   None, None, st()), "profile"), R)
+            if us < 0.8:                                     # not a launch of this plan
+                continue
+            if k == 1 and any(x["kernel"].startswith("conv1_sp_kernel") for x in kernels):      # FB_ACT_FUSED=0: the two-launch form
+                name, flop, split = "conv23_sp_kernel", c23f, 3
             # (inside fb_vec_step the head does not get a launch of its own: it rides in the env step launch)
             add(name + "[act n=1024]", us, 0 if name == "head_kernel" else 1, "mfma", flop * N_ENVS, split)
+            if k == 1 and split != 3:
+                kernels[-1]["dtype"] = "f16x2 (conv1) / f16x3 (conv2, conv3), fp32 result"
         # train step, B = 32 (forward kernels see 2B samples: s and s')
         scratch.train_step("dqn", s, a, r, s2, t, want_aux=False)
         for k in range(64):
@@ -297,23 +304,23 @@ def main():
             if us < 0.8:                                     # not a launch of this plan (rides in a neighbour at B = 32, see fb_qnet_kernel_name)
                 continue
             if name in ("conv1_pool_kernel", "conv23_t_kernel"):
-                # the train-only leg's first two launches (on a gathered minibatch); the full loop runs the ring-fed trunk below instead
+                # the gathered-minibatch form (fb_qnet_train_step on u8 states); both measured loops run the ring-fed trunk below instead
                 add(name + "[train 2B=64, gathered minibatch]", us, 0, "mfma", FWD_FLOP[name] * 2 * BATCH)
             elif name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
             elif name == "conv_bx_kernel":                    # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
-                add(name + "[+ conv3 dW + Adam of W_fc1]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
+                add(name + "[conv3^T / conv2^T chain + conv3 dW + Adam of W_fc1 (HBM part priced)]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
             elif name == "conv_dw21_kernel":
                 add(name + "[gathered minibatch]", us, 0, "mfma", BWD_FLOP[name] * BATCH)      # (full loop: the <ring> variant below)
             elif name in BWD_FLOP:
                 add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
-            elif name == "adam_kernel":
-                add(name + "[all but W_fc1]", us, 1, "hbm", ADAM_BYTES * (net.n_params - 1600 * 512))
+            elif name == "adam_fused_kernel":                 # 80 K parameters + their slab sums: a dependent-load chain, not a stream
+                add(name + "[all but W_fc1; emits the conv planes]", us, 1, "latency", ADAM_BYTES * (net.n_params - 1600 * 512))
             else:
-                add(name, us, 1, "hbm", 0)
+                add(name, us, 1, "latency", 0)
         us = ev_time(lambda: L.check(lib.fb_replay_profile_gather(replay.h, BATCH, L.ptr(idx), L.ptr(s), L.ptr(s2), L.ptr(a), L.ptr(r),
                                                                   L.ptr(t), R, st()), "gather"), R)
-        add("gather_kernel<false>[B=32]", us, 0, "hbm", GATHER_BYTES * BATCH)      # (train-only leg; the full loop has no gather launch)
+        add("gather_kernel<false>[B=32]", us, 0, "hbm", GATHER_BYTES * BATCH)      # (no loop launches it any more; callers that want the u8 minibatch)
         # what the full loop launches instead of gather + conv1 + conv2/3: the conv trunk of every sampled state, fed from the 1-bit ring
         for k, nm, flop in ((1, "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]",
                              (FWD_FLOP["conv1_pool_kernel"] + FWD_FLOP["conv23_t_kernel"]) * 2 * BATCH),
@@ -339,7 +346,7 @@ def main():
         us = ev_time(lambda: [replay.current_state() for _ in range(R)], R)
         add("gather_kernel<true>[currentState n=1024]", us, 0, "hbm", 2 * 25_600 * N_ENVS)
         us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
-        add("env_kernel<true>[n=1024]", us, 1, "hbm", ENV_BYTES * N_ENVS)
+        add("env_kernel<true>[n=1024]", us, 1, "lds", ENV_BYTES * N_ENVS)      # row-mask table lookups in LDS; 6.4 KB per env-step is no HBM load
         # prioritized replay (config 4: 1 M-slot SumTree in HBM): latency-bound tree walks -> us per batch, no BW fraction
         per = VecReplay(CAPACITY, N_ENVS, prioritized=True)
         per.seed(seed, "numpy")
@@ -350,39 +357,44 @@ def main():
         perr = torch.rand(BATCH, device="cuda")
         per.update_priorities(pidx, abs_err=perr)
         us = ev_time(lambda: [per.sample(BATCH) for _ in range(R)], R)
-        add("per_sample_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        add("per_sample_kernel[B=32, 1M-slot tree]", us, 0, "latency", 0)
         us = ev_time(lambda: [per.update_priorities(pidx, abs_err=perr) for _ in range(R)], R)
-        add("per_update_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        add("per_update_kernel[B=32, 1M-slot tree]", us, 0, "latency", 0)
         us = ev_time(lambda: [per.push(env.frame_bits, acts, env.reward, env.terminal) for _ in range(R)], R)
-        add("push_kernel + per_store_kernel[n=1024, exact order]", us, 0, "hbm", 0)
+        add("push_kernel + per_store_kernel[n=1024, exact order]", us, 0, "latency", 0)
         per.set_per_mode("fast")                             # level-wise recomputation instead of ordered running sums
         us = ev_time(lambda: [per.push(env.frame_bits, acts, env.reward, env.terminal) for _ in range(R)], R)
-        add("push_kernel + per_store_fast_kernel[n=1024]", us, 0, "hbm", 0)
+        add("push_kernel + per_store_fast_kernel[n=1024]", us, 0, "latency", 0)
         us = ev_time(lambda: [per.update_priorities(pidx, abs_err=perr) for _ in range(R)], R)
-        add("per_update_fast_kernel[B=32, 1M-slot tree]", us, 0, "hbm", 0)
+        add("per_update_fast_kernel[B=32, 1M-slot tree]", us, 0, "latency", 0)
         del per
         dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
         roofline = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}
         roofline["us"] = dom["us"]
-        for f in ("dtype", "fp32_equivalent_tflops", "note"):
+        for f in ("dtype", "frac_basis", "achieved_issued", "frac_issued", "note"):
             if f in dom:
                 roofline[f] = dom[f]
-        # the north-star HBM figure: the replay gather (102 417 logical bytes per sampled transition)
+        # the north-star HBM figure: the replay gather (102 417 logical bytes per sampled transition).  Per batch size the
+        # PMC figure comes FIRST (HBM bytes the counters saw, profiles/traffic.json, / time / 8 TB/s), the logical figure second (SURVEY's
+        # s and s' as 2 x 25 600 B read + written per transition; the ring stores a frame as 800 B of bits and shares frames between s and
+        # s', so the launch really moves far less).  B = 32 is 1 us of traffic inside a ~4 us dependent launch: latency-bound, no bandwidth
+        # claim.  The measured loops launch no gather at all: the train step reads the sampled transitions' bits in the ring directly.
         gk = {k["kernel"]: k for k in kernels}
-        # two figures per batch size, and which is which: `achieved` / `frac` price SURVEY 8(d)'s LOGICAL bytes (s and s' as 2 x 25 600
-        # B read + written per transition) -- the ring stores a frame as 800 B of bits and shares frames between s and s', so the launch
-        # really moves far less: `pmc_*` price the HBM bytes the PMC counters saw (profiles/traffic.json).  The north-star ">= 40 % of the
-        # HBM roofline" is met on the logical figure from B = 256 up and on the PMC figure at B = 4096; at B = 32 the launch is 1 us of
-        # traffic inside a ~3.5 us dependent launch: latency bound.  The measured loop itself no longer launches a
-        # gather at all: its train step reads the sampled transitions' bits in the ring directly (4 KB per transition; `ingest` below).
-        roofline["replay_gather"] = {"in_loop": "none: the conv trunk kernel reads 4 x 800 B of frame bits per state from the ring (conv23_t_kernel<ring>)"}
+        roofline["replay_gather"] = {"in_loop": "none: the conv trunk kernel reads 4 x 800 B of frame bits per state from the ring (conv23_t_kernel<ring>), "
+                                                "in fb_vec_step and in fb_train_steps alike"}
         for b, n in (("B=32", "gather_kernel<false>[B=32]"), ("B=256", "gather_kernel<false>[B=256]"), ("B=4096", "gather_kernel<false>[B=4096]")):
-            g_ = {f: gk[n][f] for f in ("achieved", "peak", "unit", "frac", "traffic", "us")}
-            g_["basis"] = "logical bytes (SURVEY 8d: 102 417 B per sampled transition)"
-            if g_["traffic"]:
-                g_["pmc_GBps"] = round(g_["traffic"] / g_["us"] / 1e3, 1)
-                g_["pmc_frac"] = round(g_["traffic"] / g_["us"] / 1e3 / HBM_PEAK_GBS, 4)
+            kk = gk[n]
+            g_ = {"us": kk["us"], "traffic": kk["traffic"]}
+            if kk["traffic"]:
+                g_["pmc_GBps"] = round(kk["traffic"] / kk["us"] / 1e3, 1)
+                g_["pmc_frac"] = round(kk["traffic"] / kk["us"] / 1e3 / HBM_PEAK_GBS, 4)
+            g_["logical_GBps"] = kk["achieved"]
+            g_["logical_frac"] = kk["frac"]
+            g_["logical_basis"] = "SURVEY 8d: 102 417 B per sampled transition"
+            if b == "B=32":
+                g_["bound"] = "latency (1 us of traffic in a dependent launch): the fractions are reported, not claimed"
             roofline["replay_gather"][b] = g_
+        roofline["grad_steps_per_sec"] = round(grad_steps_per_s, 1)      # (the train-only half of BASELINE.json's metric, where the driver's record keeps it)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
@@ -433,7 +445,10 @@ def main():
             "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",
                        "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
                        "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
-                       "train_leg": "fb_train_steps(10) in one hipGraph" if graph_used else "eager",
+                       "train_leg": "fb_train_steps(10) in one hipGraph: 10 x (random.sample -> ring-fed six-launch train step)" if graph_used else "eager",
+                       "train_only": {"grad_steps_per_sec": round(grad_steps_per_s, 1), "us_per_grad_step": round(1e6 * world / grad_steps_per_s, 2),
+                                      "grad_steps_per_sec_eager": round(grad_steps_eager, 1)},
+                       "env_only_steps_per_sec": round(env_only, 1),
                        "parallelism": (f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat gradient per step"
                                        + (" (fb_vec_step_dp: issued from the C side in two pieces, the W_fc1 / head part overlapped with the conv backward)"
                                           if native is not None else " (torch.distributed)")) if world > 1 else "single GPU"},

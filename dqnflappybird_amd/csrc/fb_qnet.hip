@@ -552,6 +552,10 @@ struct C23Args {
     const unsigned *pver; unsigned *wver;    // whole forward plans: the conv1 launch in front re-split the weights if these differed
     unsigned *wverc;                         // (the conv part's own version word, see AdamDev)
     float *h2o, *h3o;                        // training: fp32 copies of conv2's / conv3's output rows [n*25][64] for the backward pass, or NULL
+    // C1 = true (the acting path on nibble states): conv1 + pool of the workgroup's states run HERE, in front of conv2 -- their output
+    // goes straight into conv2's LDS image and never sees HBM (p1s / pl1 unused)
+    const uint8_t *nib; const uint16_t *w1s; const float *b1;
+    const float *params; uint4 *wsp; int FC;  // ... and the riding re-split of W_fc1's planes for the fc1 launch that follows (pver != wver)
 };
 
 #ifndef C23_NO_LDSR
@@ -569,12 +573,22 @@ struct C23Args {
 #ifndef C23_EXIT
 #define C23_EXIT 0
 #endif
-template <int NS>
+// SPW = states per workgroup (5: 125 of the 128 MFMA rows; the fused acting trunk takes 4: 1024 envs = 256 workgroups = every CU).
+// C1 = true: THE ACTING TRUNK -- conv1 + pool of the SPW states run in this kernel too, on the SAME-padded nibble states (one byte = 2
+// pixels x 4 frames; the MFMA operand is a 256-entry table lookup, as in conv1_sp_kernel<nib>): 8 waves x 6-7 tiles of 8 pooled pixels,
+// each wave holding all 32 weight fragments of W_conv1's two planes in REGISTERS for its tiles (conv1_sp_kernel re-reads them from LDS
+// for every tile: 32 KB of LDS reads per tile, 2.4 MB per CU -- that kernel is as much LDS- as MFMA-bound), and the pooled output is
+// split straight into conv2's LDS image: the 13 + 13 MB of fp16 planes conv1_sp_kernel writes and this kernel read back, and one
+// launch boundary, are gone.  The nibble images, the table and the staged conv1 weights live where the weight ring and the exchange
+// area will be (both idle until conv2 starts).
+template <int NS, int SPW = 5, bool C1 = false>
 __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
     // NS = 3: fp32-equivalent arithmetic on two fp16 planes (h, l; three products per step); NS = 1: one bf16 plane
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;             // operand planes in use / first weight plane of wsp
-    constexpr int IN_P = 2000, C2_P = 1000, ZOFF = NPL * IN_P, RING = ZOFF + 16, RSZ = 4 * NPL * 64, XCH = RING + 6 * RSZ;   // uint4 units
+    constexpr int IN_P = SPW * 400, C2_P = SPW * 200, ZOFF = NPL * IN_P, RING = ZOFF + 16, RSZ = 4 * NPL * 64, XCH = RING + 6 * RSZ;   // uint4 units
     constexpr int NOWN = 17;                 // chunks per wave group
+    constexpr int NIB_U4 = FB_NIB_STRIDE / 16, NIBO = RING, LUTO = RING + SPW * NIB_U4;      // (C1) nibble images and table inside the ring area
+    static_assert(FB_NIB_STRIDE % 16 == 0 && SPW * NIB_U4 + 256 <= 6 * RSZ, "the conv1 front end borrows the weight ring");
     __shared__ uint4 smem[XCH + 2048];
     // EIGHT waves: wave group g = wave >> 2 takes the chunks of parity g (conv2 taps 2 i + g, then conv3 half taps 2 k + g) for the same
     // four 32-row tiles, so every SIMD holds two waves (w and w + 4) whose LDS reads, ring writes and barrier waits hide behind each
@@ -582,11 +596,11 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
     // of MFMAs; ablation builds -DC23_NO_*).  The two partial sums per output meet through LDS once per convolution; each wave then
     // finishes the channel tile ct = g.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w4 = wave & 3, grp = wave >> 2, hl = lane >> 5, j = lane & 31;
-    const int s0 = blockIdx.x * 5, ml = w4 * 32 + j;
-    if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) { *a.wver = *a.pver; *a.wverc = *a.pver; }
+    const int s0 = blockIdx.x * SPW, ml = w4 * 32 + j;
+    if (!C1 && a.wver && blockIdx.x == 0 && threadIdx.x == 0) { *a.wver = *a.pver; *a.wverc = *a.pver; }
     const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
-    const bool rowok = ml < 125;
-    int nloc = a.n - s0; if (nloc > 5) nloc = 5;
+    const bool rowok = ml < SPW * 25;
+    int nloc = a.n - s0; if (nloc > SPW) nloc = SPW;
     const int ringp = RING + grp * 3 * RSZ;  // this group's three ring slots
     // weight staging registers: named members, no arrays (hipcc otherwise parks them in LDS / scratch)
     struct BSt { uint4 v0, v1; };
@@ -606,6 +620,77 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
         if (NPL == 2) d[256] = r.v1;
     };
     BSt bstA = loadB(0), bstB = loadB(1);
+    if constexpr (C1) {
+        // ---- conv1 + bias + relu + 2x2 max pool of the workgroup's states, into conv2's LDS image
+        // W_fc1's planes for the fc1 launch that follows, if the parameters moved since they were split (decided on the device; the fc1
+        // launch records the new version): at most one 8-weight item per thread, requested first
+        if (a.pver && *a.pver != *a.wver)
+            for (int id = IT_CONV + blockIdx.x * 512 + threadIdx.x; id < IT_CONV + 200 * a.FC; id += gridDim.x * 512) wsplit_item(a.params, a.wsp, a.FC, id);
+        const uint4 *w1g = reinterpret_cast<const uint4 *>(a.w1s);
+        const uint4 wc0 = w1g[threadIdx.x], wc1 = w1g[threadIdx.x + 512], wc2 = w1g[threadIdx.x + 1024], wc3 = w1g[threadIdx.x + 1536];
+        const uint4 *ng = reinterpret_cast<const uint4 *>(a.nib + (size_t)s0 * FB_NIB_STRIDE);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 512;            // (SPW * NIB_U4 = 928 entries: two per thread)
+        static_assert(SPW * NIB_U4 <= 1024, "two image entries per thread");
+        const uint4 n0 = ng[i0 < nloc * NIB_U4 ? i0 : 0], n1 = ng[i1 < nloc * NIB_U4 ? i1 : 0];
+        smem[XCH + threadIdx.x] = wc0; smem[XCH + threadIdx.x + 512] = wc1; smem[XCH + threadIdx.x + 1024] = wc2; smem[XCH + threadIdx.x + 1536] = wc3;
+        if (i0 < SPW * NIB_U4) smem[NIBO + i0] = i0 < nloc * NIB_U4 ? n0 : make_uint4(0u, 0u, 0u, 0u);
+        if (i1 < SPW * NIB_U4) smem[NIBO + i1] = i1 < nloc * NIB_U4 ? n1 : make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x < 256) smem[LUTO + threadIdx.x] = nib_lut_entry(threadIdx.x);
+        if (threadIdx.x < 16) smem[ZOFF + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (nloc < SPW)                          // the last workgroup of a count that SPW does not divide: rows of absent states compute on zeros
+            for (int i = threadIdx.x; i < NPL * IN_P; i += 512) smem[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        // this wave's copy of the 16 h-plane weight fragments ([c = (ky, kq)][lane]) stays in REGISTERS for all its tiles; the 16 l-plane
+        // fragments are re-read from LDS per tile (all 32 in registers, 128 VGPRs, spill beside what the conv2 / conv3 pipeline holds)
+        uint4 Wf[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) Wf[c] = smem[XCH + c * 64 + lane];
+        const uint8_t *nibl = reinterpret_cast<const uint8_t *>(smem + NIBO);
+        const uint4 *lut = smem + LUTO;
+        const float bias1 = a.b1[j];
+        const int npool = nloc * 100, ntile = (npool + 7) >> 3;
+        for (int tile = wave; tile < ntile; tile += 8) {
+            const int P = tile * 8 + (j >> 2), pos = j & 3, Pc = P < npool ? P : 0;
+            const int st = Pc / 100, r100 = Pc - st * 100, py = r100 / 10, px = r100 - py * 10, poy = 2 * py + (pos >> 1), pox = 2 * px + (pos & 1);
+            // the image carries conv1's SAME padding: every tap is base + ky * pitch + 2 * kq (include/fbdqn.h FB_NIB_*)
+            const uint8_t *base = nibl + st * FB_NIB_STRIDE + (4 * poy) * FB_NIB_PITCH + 3 + 2 * pox + hl;
+            unsigned raw[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) raw[c] = base[(c >> 1) * FB_NIB_PITCH + 2 * (c & 1)];
+            f32x16 c1a = {0}, c1l = {0};
+            int z;                                   // opaque 0: keeps the l-plane fragments in LDS (re-read per tile) instead of hoisted into registers
+            asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+            const uint4 *wl1 = smem + XCH + 16 * 64 + lane + z;
+#pragma unroll
+            for (int h8 = 0; h8 < 2; h8++) {
+                uint4 A[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) A[c] = lut[P < npool ? raw[8 * h8 + c] : 0u];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    c1a = mfma_h(A[c], Wf[8 * h8 + c], c1a);
+                    c1l = mfma_h(A[c], wl1[(8 * h8 + c) * 64], c1l);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) c1a[r] = fmaf(c1l[r], F16_LO_UNSCALE, c1a[r]);      // x*wh + (x*wl) / 4096: exact scale, one rounding
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                // register r of a lane = window position r & 3 of pooled pixel 2 * (r >> 2) + hl, channel j: the pool is a max over four
+                // registers; relu(max + bias) == max of the relu'd values (monotone)
+                const float bv = fmaxf(fmaxf(fmaxf(c1a[4 * g], c1a[4 * g + 1]), fmaxf(c1a[4 * g + 2], c1a[4 * g + 3])) + bias1, 0.f);
+                const int Pp = tile * 8 + 2 * g + hl;
+                if (Pp < npool) {
+                    uint16_t *d = reinterpret_cast<uint16_t *>(smem + Pp * 4 + (((j >> 3) + (Pp >> 2)) & 3)) + (j & 7);
+                    if constexpr (NS == 3) {
+                        const _Float16 hh = (_Float16)bv, ll = (_Float16)((bv - (float)hh) * F16_LO_SCALE);
+                        d[0] = __builtin_bit_cast(uint16_t, hh); d[IN_P * 8] = __builtin_bit_cast(uint16_t, ll);
+                    } else d[0] = (uint16_t)f32_to_bf16_rn(bv);
+                }
+            }
+        }
+        __syncthreads();                         // the image is complete, and every wave is done with the ring area
+    } else
     {   // the five input images, plane by plane; piece q of pixel pix lands on piece (q + (pix >> 2)) & 3
         uint4 t[NPL][4];
 #pragma unroll
@@ -1013,7 +1098,8 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
 // software pipeline (fragments of chunk c + 1 read while chunk c is in the MFMAs, chunk c + 2 written to its ring
 // slot, chunk c + 4 in flight from global).  A slice with only 12 chunks runs its 13th on the zero page.
 constexpr int FC1_SP_KS = 4;
-struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; const uint4 *w; float *hfp; int stot, M, N; };
+struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; const uint4 *w; float *hfp; int stot, M, N;
+                 const unsigned *pver; unsigned *wver; };       // (behind the fused acting trunk, which re-split W_fc1's planes if they were stale: record it)
 
 template <int NS>
 __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
@@ -1021,6 +1107,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     constexpr int ASZ = NPL * 512, BSZ = 4 * NPL * 64, SLOT = ASZ + BSZ;         // uint4 units
     __shared__ uint4 smem[3 * SLOT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
+    if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) *a.wver = *a.pver;
     // XCD-aware tile order (consecutive workgroup ids go round the 8 XCDs, each with its own 4 MB L2): XCD x takes K slice
     // x & 3 and the column tiles of half x >> 2, for every row tile -- 0.6 MB of weights + 2.4 MB of activations per L2
     // instead of all 4.9 MB of weights behind each one (row-tile-major order: 49 MB through the fabric per 1024 states)
@@ -2149,7 +2236,7 @@ __device__ __forceinline__ void adam4(float4 &P, float4 &Mv, float4 &V, const fl
 // W_fc1 is 91 % of the parameters and its gradient is complete once the fc1 backward launch has run, while the launches
 // that follow (conv3 / conv2 / conv1 backward) neither read W_fc1 nor fill more than ~200 of the 256 CUs, and wait on
 // latency rather than on HBM.  Its Adam update therefore rides as extra workgroups at the END of the conv3 backward
-// launch (float4 range [q0, q1) of the flat parameter vector); adam_kernel at the end of the step skips that range.
+// launch (float4 range [q0, q1) of the flat parameter vector); adam_fused_kernel at the end of the step skips that range.
 struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; };
 __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan a) {
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
@@ -2540,64 +2627,20 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_
     grad[idx] = s;
 }
 
-// TF ApplyAdam, fp32, float4 wide.  When `slabs` is given the conv gradients are still spread over the
-// reduction slabs of conv_dw_kernel: they are summed here, in slab order, instead of in a separate launch.
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
-                                                   const float *__restrict__ g, long long n, AdamDev *__restrict__ ad,
-                                                   const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
-                                                   uint16_t *__restrict__ w1s, int skip0, int skip1, int n_adam_blocks,
-                                                   FbGatherRider gr) {
-    // fb_train_steps: the NEXT step's minibatch gather rides behind the Adam blocks (its indices were drawn in the conv3
-    // backward launch; nothing of this step reads the minibatch buffers any more)
-    if ((int)blockIdx.x >= n_adam_blocks) {
-        gather_body<false>(gr.c, gr.steps, gr.B, gr.idx, (uint4 *)gr.s, (uint4 *)gr.s2, gr.a, gr.r, gr.t,
-                           (long long)((int)blockIdx.x - n_adam_blocks) * 256 + threadIdx.x);
-        return;
-    }
-    const float alpha = ad->alpha, omb1 = 1.f - ad->b1, omb2 = 1.f - ad->b2, eps = ad->eps;
-    const long long n4 = n >> 2, nq = n4 - (skip1 - skip0);      // float4s [skip0, skip1) were updated by an AdamSpan already
-    for (long long qq = (long long)blockIdx.x * 256 + threadIdx.x; qq < nq; qq += (long long)n_adam_blocks * 256) {
-        const long long q = qq < skip0 ? qq : qq + (skip1 - skip0);
-        float4 P = reinterpret_cast<float4 *>(p)[q], Mv = reinterpret_cast<float4 *>(m)[q], V = reinterpret_cast<float4 *>(v)[q];
-        float4 Gv;
-        if (slabs && q * 4 < CONV_PARAMS) {                      // region boundaries are multiples of 4
-            const int idx = (int)q * 4, z = idx < OFF_W2 ? z1 : (idx < OFF_W3 ? z2 : z3);
-            Gv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int s = 0; s < z; s++) {
-                const float4 t = *reinterpret_cast<const float4 *>(slabs + s * slab_stride + idx);
-                Gv.x += t.x; Gv.y += t.y; Gv.z += t.z; Gv.w += t.w;
-            }
-        } else Gv = reinterpret_cast<const float4 *>(g)[q];
-        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
-        reinterpret_cast<float4 *>(p)[q] = P; reinterpret_cast<float4 *>(m)[q] = Mv; reinterpret_cast<float4 *>(v)[q] = V;
-        if (q * 4 < OFF_B1) {                                    // W_conv1 changed: refresh its two fp16 planes
-            const int idx = (int)q * 4;
-            split_w1(P.x, idx, w1s); split_w1(P.y, idx + 1, w1s); split_w1(P.z, idx + 2, w1s); split_w1(P.w, idx + 3, w1s);
-        }
-    }
-    // the update consumes the pending tick and makes a new parameter version (nothing in this launch reads either word)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ad->applies = ad->ticks; ad->pver[0] += 1; }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const long long q = (n4 << 2) + threadIdx.x;
-        float mm = m[q], vv = v[q];
-        mm += (g[q] - mm) * omb1; vv += (g[q] * g[q] - vv) * omb2;
-        p[q] -= (mm * alpha) / (sqrtf(vv) + eps);
-        m[q] = mm; v[q] = vv;
-    }
-}
-
-// The FUSED step's Adam launch (single GPU: the gradient never leaves the step).  Same arithmetic per element as adam_kernel -- adam4 on
-// the slab sums in slab order / the flat gradient -- dealt out differently, so that the update of W_conv2 / W_conv3 can leave their
-// split planes behind (forward [k / 8][plane][co] and transposed [tap * 8 + co / 8][plane][ci], what wsplit_item builds) the way the
-// update of W_conv1 always has (split_w1): a train step that follows WITHOUT an acting forward in between -- the train-only loop,
-// fb_train_steps -- can then start with the ring-fed conv trunk, which reads those planes and has no launch in front of it that could
-// refresh them.  W_fc1's planes stay stale (wver): only the >= 256-state forward reads them, and its conv1 launch re-splits on sight.
+// TF ApplyAdam, fp32, float4 wide: THE Adam launch -- of the fused step (single GPU: the conv gradients are still spread over the
+// reduction slabs and are summed here, in slab order; W_fc1 has been updated by the AdamSpan riding in the conv3 backward launch and
+// is skipped: tail0) and of fb_qnet_apply_adam (data parallel: a complete flat gradient, no slabs, tail0 = the start of W_fc1).
+// adam4 per element either way, dealt out so that the update of W_conv2 / W_conv3 leaves their split planes behind (forward
+// [k / 8][plane][co] and transposed [tap * 8 + co / 8][plane][ci], what wsplit_item builds) the way the update of W_conv1 always has
+// (split_w1).  INVARIANT this establishes: the conv planes of a net are current after every library call that writes its parameters
+// (Adam here; init / load / target sync re-split eagerly) -- so the kernels that read them in the launch they run in (the ring-fed
+// train trunk conv23_t_kernel<ring>, the fused acting trunk) need no launch in front of them.  W_fc1's planes stay stale (wver): only
+// the >= 256-state forward reads them, and the launch in front of its fc1 re-splits them on sight.
 //   workgroups [0, 32)      W_conv2, one tile of 16 k-rows x 64 co each (1024 weights): update, park the new values in LDS, emit the
 //                           2 x 64 forward entries and the 16 x 8 transposed entries (8 weights each, three planes)
 //   workgroups [32, 68)     W_conv3 likewise (36 tiles)
-//   then n_rest             everything else but W_fc1 (the AdamSpan riding in the conv3 backward launch has updated it): W_conv1 +
-//                           b_conv1 (slab sums; W_conv1's planes via split_w1), b_conv2, b_conv3, b_fc1 and the head
+//   then n_rest             everything else from tail0 on: W_conv1 + b_conv1 (W_conv1's planes via split_w1), b_conv2, b_conv3, [W_fc1,]
+//                           b_fc1 and the head
 //   then                    fb_train_steps' gather rider, if any
 constexpr int ADAMF_T2 = 32, ADAMF_T3 = 36;
 struct AdamFused {
@@ -2974,19 +3017,26 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             if (z1 - z0 > 1) { side.per = s0.count; side.st1 = p.sl.s[z0 + 1].states; side.st2 = z1 - z0 > 2 ? p.sl.s[z0 + 2].states : p.sl.s[z0 + 1].states; }
             if (p.train) { side.p1 = h->p1; side.amax = h->amax; }
             const int t1p = (rows * 100 + 7) / 8, gsp = min(256, (t1p + C1_WAVES - 1) / C1_WAVES);      // one 12-wave workgroup per CU, the waves stride over the tiles
-            if (!trunk) FB_K(K_CONV1) {
+            // the acting path on nibble states: conv1 + conv2 + conv3 in ONE launch (conv23_sp_kernel<., 4, true>), four states per workgroup
+            static const bool fuse_on = !(getenv("FB_ACT_FUSED") && atoi(getenv("FB_ACT_FUSED")) == 0);      // A/B knob
+            const bool fused = fuse_on && p.nib && !p.train && !trunk && z1 - z0 == 1;
+            if (!trunk && !fused) FB_K(K_CONV1) {
                 if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
                 else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
             }
             C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver, only < 0 ? &h->adam->wverc[which] : nullptr,
-                        p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr};
-            Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC};
-            const dim3 gc((rows + 4) / 5), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
+                        p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr,
+                        s0.states, s0.w1s, s0.params + OFF_B1, s0.params, h->wsp[which], h->FC};
+            Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC,
+                       fused ? pver : nullptr, fused ? wver : nullptr};
+            const dim3 gc((rows + 4) / 5), gc4((rows + 3) / 4), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
-                if (!trunk) FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23);      // conv3 rides in the same launch
+                if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 4, true>), gc4, dim3(512), 0, st, c23); }      // conv1 .. conv3
+                else if (!trunk) { FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23); }      // conv3 rides in the same launch
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
             } else {
-                if (!trunk) FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23);
+                if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<1, 4, true>), gc4, dim3(512), 0, st, c23); }
+                else if (!trunk) { FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23); }
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
             }
             z0 = z1;
@@ -3211,8 +3261,12 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     (void)hipStreamIsCapturing(st, &cap);
     if (!h->adam_ticked || cap != hipStreamCaptureStatusNone) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->adam);
     h->adam_ticked = false;
-    hipLaunchKernelGGL(adam_kernel, dim3(ADAM_GRID), dim3(256), 0, st, h->params[0], h->adam_m, h->adam_v, flat_grad, h->n, h->adam,
-                       (const float *)nullptr, (size_t)0, 0, 0, 0, h->w1s[0], 0, 0, ADAM_GRID, FbGatherRider{});
+    AdamFused af;
+    af.p = h->params[0]; af.m = h->adam_m; af.v = h->adam_v; af.g = flat_grad; af.n = h->n; af.ad = h->adam;
+    af.slabs = nullptr; af.slab_stride = 0; af.z1 = af.z2 = af.z3 = 0;
+    af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = h->FC; af.tail0 = OFF_WF1 / 4;
+    af.n_rest = ADAM_GRID;
+    hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest), dim3(256), 0, st, af, FbGatherRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

@@ -215,10 +215,13 @@ def test_vecbrain_save_load_continues_bit_for_bit(torch_cuda, tmp_path):
     assert (a.env.get_state() == b.env.get_state()).all() and len(a.replay) == len(b.replay)
 
 
-@pytest.mark.parametrize("N", [7, 64, 300])      # < 256: the fp32-MFMA kernels; >= 256: the split-bf16 acting kernels
+@pytest.mark.parametrize("N", [7, 64, 300, 301, 1027])      # < 256: the small-batch kernels; >= 256: the two-plane fp16 acting kernels
 def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cuda, N):
     """The env kernel's running 4-frame nibble state == the replay ring's currentState (BrainDQN.py:68,238-239),
-    and the acting forward that consumes it gives bit-identical Q / actions to the u8 path."""
+    and the acting forward that consumes it gives bit-identical Q / actions to the u8 path.  (>= 256 states the nibble path is the
+    FUSED trunk -- conv1 + conv2 + conv3 in one launch, four states per workgroup, conv1's output handed over in LDS -- and the u8
+    path the conv1 launch + the five-states-per-workgroup conv2 / conv3 launch with fp16 planes in HBM between them: same bits.
+    301 / 1027: a last workgroup with one / three states.)"""
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
     env, rep, net = VecGameState(N, seed=3), VecReplay(5000, N), QNet(max_batch=max(N, 8))
