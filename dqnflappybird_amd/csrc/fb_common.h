@@ -87,7 +87,6 @@ int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a,
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, const float *isw, double gamma, float *loss,
                             float *abs_err, float *flat_grad, void *stream, const FbSampleRider *rider = nullptr);
 int fb_qnet_refresh_planes(fb_qnet_t h, void *stream);      // re-split whichever net's planes are stale (decided on the device)
-int fb_qnet_refresh_conv_planes(fb_qnet_t h, void *stream); // the same for the W_conv2 / W_conv3 planes alone (all the ring-fed conv trunk needs)
 int fb_qnet_profile_ring(fb_qnet_t h, int kernel, int reps, int algo, int batch, const FbRingSrc *ring, float *loss, void *stream);
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
 // into the ring slot of the coming push (bits: slot of env 0's frame, +100 words per env; act / rew / term: row of the
@@ -106,6 +105,7 @@ int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch);
 int fb_env_num_envs(fb_env_t h);
 int fb_replay_num_envs(fb_replay_t h);
 int fb_replay_is_prioritized(fb_replay_t h);
+int fb_replay_per_store_ahead(fb_replay_t h, void *stream);      // the tree part of the coming push, ahead of it on a side stream (see fb_replay.hip)
 int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,

@@ -94,8 +94,8 @@ void fb_mt_init_by_array_host(FbMT *s, const uint32_t *key, int key_length) {
 // launches of the ring-fed train step (conv trunk of the 2B states straight from the 1-bit frame ring -> fc1 -> loss + fc1 backward ->
 // conv data gradients -> conv weight gradients -> Adam): no gather, no u8 minibatch.  Only the first draw gets a launch of its own: the
 // draw for step i + 1 rides in step i's conv3 backward launch (it needs the generator and len(memory), nothing of step i).  What lets
-// a step start with the trunk: the fused Adam launch leaves the split planes of W_conv1 / W_conv2 / W_conv3 behind
-// (adam_fused_kernel), so they are current without an acting forward in between; whatever was stale on entry is re-split once here.
+// a step start with the trunk: the Adam launch leaves the split planes of W_conv1 / W_conv2 / W_conv3 behind (adam_fused_kernel), and
+// every other writer of the parameters re-splits eagerly, so the conv planes are current without an acting forward in between.
 // idx holds two index buffers used alternately; the indices of step i end up in idx[(i & 1) * batch ..).  s / s2 (the u8 minibatch
 // of the gathered form) are only written when FB_TRAIN_STEPS_GATHER=1 selects that form (A/B knob: 7 launches per step).
 extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int batch, int n_steps, int64_t *idx, uint8_t *s,
@@ -105,7 +105,6 @@ extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int b
     static const bool gathered_form = getenv("FB_TRAIN_STEPS_GATHER") && atoi(getenv("FB_TRAIN_STEPS_GATHER")) == 1;
     int rc = fb_replay_sample(replay, batch, nullptr, idx, nullptr, stream);
     if (!gathered_form) {
-        if (rc == FB_OK) rc = fb_qnet_refresh_conv_planes(net, stream);
         for (int i = 0; rc == FB_OK && i < n_steps; i++) {
             int64_t *cur = idx + (size_t)(i & 1) * batch, *nxt = idx + (size_t)((i + 1) & 1) * batch;
             FbRingSrc ring;
@@ -158,6 +157,10 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
         const int rc0 = fb_qnet_check_step(net, n_envs, train ? batch : -1);
         if (rc0 != FB_OK) return rc0;
     }
+    // prioritized memory: Memory.store's tree update of this step's push goes out FIRST, on the memory's side stream -- it depends on the
+    // tree as the previous step left it and on the env count, nothing else -- and runs beside the acting forward and the env step
+    static const bool store_ahead = !(getenv("FB_PER_STORE_AHEAD") && atoi(getenv("FB_PER_STORE_AHEAD")) == 0);      // A/B knob
+    if (per && store_ahead) (void)fb_replay_per_store_ahead(replay, stream);
     // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
     // every env has a workgroup of its own there
     FbHeadRider hrider;
@@ -223,8 +226,12 @@ extern "C" int fb_train_from_replay(fb_replay_t replay, fb_qnet_t net, int algo,
     FbRingSrc ring;
     int rc = fb_replay_ring_src(replay, batch, idx, a, r, t, &ring);
     if (rc != FB_OK) return rc;
-    rc = fb_qnet_refresh_planes(net, stream);       // (fb_vec_step needs no such launch: its acting forward has just done it)
-    if (rc != FB_OK) return rc;
+    // the conv planes are always current (adam_fused_kernel; init / load / sync re-split eagerly).  Only a batch of >= 256 also reads
+    // W_fc1's planes (fc1_sp_kernel), which Adam leaves stale: re-split them on sight (two guarded launches)
+    if (batch >= 256) {
+        rc = fb_qnet_refresh_planes(net, stream);
+        if (rc != FB_OK) return rc;
+    }
     return fb_qnet_train_step_ring(net, algo, batch, &ring, isw, gamma, loss, abs_err, flat_grad, stream);
 }
 

@@ -3331,27 +3331,6 @@ int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring,
     return run_plan(h, p, -1, fb_stream(stream));
 }
 
-// the conv part of both nets' planes alone (W_conv2 / W_conv3, forward + transposed): what the ring-fed conv trunk reads.  Guarded on
-// the device by AdamDev::pver / wverc -- after a fused step (adam_fused_kernel emits these planes) the launch returns at once.
-__global__ void wsplit_conv_both_kernel(const float *__restrict__ p0, const float *__restrict__ p1, uint4 *__restrict__ w0, uint4 *__restrict__ w1, int FC,
-                                        const AdamDev *__restrict__ ad) {
-    const int n = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ad->pver[n] == ad->wverc[n] || q >= 2 * IT_CONV) return;
-    wsplit_item(n ? p1 : p0, n ? w1 : w0, FC, conv_item(q, FC));
-}
-__global__ void mark_conv_split_both_kernel(AdamDev *ad) {
-    const int n = threadIdx.x;
-    if (n < 2) ad->wverc[n] = ad->pver[n];
-}
-int fb_qnet_refresh_conv_planes(fb_qnet_t h, void *stream) {
-    FB_REQUIRE(h, "fb_qnet_refresh_conv_planes: NULL handle");
-    hipLaunchKernelGGL(wsplit_conv_both_kernel, dim3((2 * IT_CONV + 255) / 256, 2), dim3(256), 0, fb_stream(stream), h->params[0], h->params[1], h->wsp[0],
-                       h->wsp[1], h->FC, (const AdamDev *)h->adam);
-    hipLaunchKernelGGL(mark_conv_split_both_kernel, dim3(1), dim3(64), 0, fb_stream(stream), h->adam);
-    FB_LAUNCH_CHECK();
-    return FB_OK;
-}
-
 // both nets in one launch (blockIdx.y = net; every thread checks its net's versions) + one marking launch
 __global__ void wsplit_both_kernel(const float *__restrict__ p0, const float *__restrict__ p1, uint4 *__restrict__ w0, uint4 *__restrict__ w1, int FC,
                                    const AdamDev *__restrict__ ad) {

@@ -585,6 +585,11 @@ struct fb_replay {
     FbMT *h_mt;
     long long host_steps;            // pushes since the last reset (mirror of ReplayDev::steps)
     int per_mode;                    // FB_PER_EXACT | FB_PER_FAST
+    // prioritized memories: Memory.store's TREE part of the coming push can run ahead of it on a stream of its own
+    // (fb_replay_per_store_ahead): it needs the tree and the number of envs, nothing of the frames
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_store;
+    bool store_ahead;                // the tree part of the next fb_replay_push has been issued already; that push joins it
 };
 
 extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out) {
@@ -622,6 +627,19 @@ extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_repla
         fb_replay_destroy(h);
         return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
     }
+    if (kind == FB_REPLAY_PER) {
+        // (highest priority: the store is ONE workgroup; when it becomes ready together with the acting forward's thousand it must get its
+        // CU first -- behind them it would wait until that launch drains, and most of what it could hide would be over)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_store, hipEventDisableTiming) != hipSuccess) {
+            fb_set_error(FB_ERR_HIP, "fb_replay_create: stream / event creation failed");
+            fb_replay_destroy(h);
+            return FB_ERR_HIP;
+        }
+    }
     *out = h;
     int rc = fb_replay_seed(h, kind == FB_REPLAY_PER ? FB_RNG_NUMPY : FB_RNG_CPYTHON, 0);
     if (rc != FB_OK) return rc;
@@ -633,6 +651,9 @@ extern "C" int fb_replay_destroy(fb_replay_t h) {
     ReplayParams &P = h->P;
     void *ptrs[] = {P.bits, P.act, P.rew, P.term, P.dev, P.mt, P.tree, P.maxt, P.mint};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_store) (void)hipEventDestroy(h->ev_store);
     delete h;
     return FB_OK;
 }
@@ -689,11 +710,33 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
     FB_LAUNCH_CHECK();
     h->host_steps += 1;
     if (P.kind == FB_REPLAY_PER) {
+        if (h->store_ahead) {                    // the tree part ran ahead on the side stream: whatever follows this push waits for it
+            h->store_ahead = false;
+            FB_CHECK_HIP(hipStreamWaitEvent(st, h->ev_store, 0));
+            return FB_OK;
+        }
         if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
         else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
         FB_LAUNCH_CHECK();
     }
     return FB_OK;
+}
+
+// Memory.store's tree work for the NEXT fb_replay_push, issued now on the memory's side stream behind everything `stream` holds so far
+// (BrainPrioritizedReplyDQN.py:121-125: p = max over the leaves, add(p, .) for each new transition -- nothing of the transition itself
+// enters the tree).  One vector step's store is one workgroup walking the root's chain of n_envs ordered fp64 additions (17 us at
+// 1024 envs, 64 us at 4096): issued here, at the top of fb_vec_step, it runs beside the acting forward and the env step instead of
+// between the env step and Memory.sample.  The push that follows joins it.  Returns 1 when issued (prioritized memories), else 0.
+int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
+    // (reference-order mode only: the level-wise FB_PER_FAST store takes ~8 us, less than the two cross-stream hops cost)
+    if (!h || h->P.kind != FB_REPLAY_PER || h->store_ahead || h->per_mode == FB_PER_FAST) return 0;
+    hipStream_t st = fb_stream(stream);
+    if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;
+    if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
+    else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
+    if (hipEventRecord(h->ev_store, h->side) != hipSuccess) { (void)hipStreamWaitEvent(st, h->ev_fork, 0); return 0; }
+    h->store_ahead = true;
+    return 1;
 }
 
 static long long cpython_setsize(int batch) {

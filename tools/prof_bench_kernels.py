@@ -19,7 +19,7 @@ for t in range(5):
     idx, _ = replay.sample(B)
     s, aa, r, s2, tt = replay.gather(idx)
     net.train_step("dqn", s, aa, r, s2, tt, want_aux=False)
-    train_from_replay(replay, net, "dqn", idx)        # the ring-fed step the full loop runs (conv23_t_kernel<3, true>, conv_dw21_kernel<2, true>)
+    train_from_replay(replay, net, "dqn", idx)        # the ring-fed step both loops run (conv23_t_kernel<3, true, true>, conv_dw21_kernel<2, true>)
 big = torch.randint(0, 40000, (4096,), dtype=torch.int64, device="cuda")
 mid = torch.randint(0, 40000, (256,), dtype=torch.int64, device="cuda")
 for _ in range(3):

@@ -3,7 +3,7 @@ MI355X_MICROARCH.md prescribes): bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 --
 coalesced reads (the factor 2; uncalibrated for narrow loads, so the read side is an upper bound).  Writes gpurun_out/<tag>_traffic.json
 (keyed by bench.py's kernel labels) and gpurun_out/<tag>_pmc_fetch_write_raw.json (per kernel name); copy both into profiles/."""
 import collections, csv, glob, json, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def mean_counter(dirpat, cname):
@@ -33,16 +33,18 @@ def pick(prefix, grid_pred=lambda g: True):
 small = lambda g: g < 200000
 t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, two separate rocprofv3 --pmc passes (tools/profile_round.sh); "
               "FETCH_SIZE halves wide coalesced reads on gfx950 (MI355X_MICROARCH.md), hence the factor 2; upper bound for narrow loads.",
-     "conv1_sp_kernel<nib>[act n=1024]": pick("conv1_sp_kernel<true>"), "conv23_sp_kernel[act n=1024]": pick("conv23_sp_kernel<3>"),
+     "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 4 states per workgroup][act n=1024]": pick("conv23_sp_kernel<3, 4, true>"),
+     "conv1_sp_kernel<nib>[act n=1024]": pick("conv1_sp_kernel<true>"), "conv23_sp_kernel[act n=1024]": pick("conv23_sp_kernel<3, 5, false>"),
      "fc1_sp_kernel[act n=1024]": pick("fc1_sp_kernel<3>"), "head_kernel[act n=1024]": pick("head_kernel"),
      "env_kernel<true>[n=1024]": pick("env_kernel<true>"),
      "conv1_pool_kernel[train 2B=64, gathered minibatch]": pick("conv1_pool_kernel<false>"),
-     "conv23_t_kernel[train 2B=64, gathered minibatch]": pick("conv23_t_kernel<3, false>"),
-     "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]": pick("conv23_t_kernel<3, true>"),
+     "conv23_t_kernel[train 2B=64, gathered minibatch]": pick("conv23_t_kernel<3, false"),
+     "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]": pick("conv23_t_kernel<3, true"),
      "fc1_fk_kernel[train 2B=64]": pick("fc1_fk_kernel"),
-     "fc1_bwd2_kernel": pick("fc1_bwd2_kernel"), "conv_bx_kernel[+ conv3 dW + Adam of W_fc1]": pick("conv_bx_kernel<3>"),
+     "fc1_bwd2_kernel": pick("fc1_bwd2_kernel"),
+     "conv_bx_kernel[conv3^T / conv2^T chain + conv3 dW + Adam of W_fc1 (HBM part priced)]": pick("conv_bx_kernel<3>"),
      "conv_dw21_kernel[gathered minibatch]": pick("conv_dw21_kernel<2, false>"), "conv_dw21_kernel<ring>": pick("conv_dw21_kernel<2, true>"),
-     "adam_kernel[all but W_fc1]": pick("adam_kernel"),
+     "adam_fused_kernel[all but W_fc1; emits the conv planes]": pick("adam_fused_kernel"),
      "gather_kernel<false>[B=32]": pick("gather_kernel<false>", lambda g: g < 100000),
      "gather_kernel<false>[B=256]": pick("gather_kernel<false>", lambda g: 100000 < g < 1000000),
      "gather_kernel<false>[B=4096]": pick("gather_kernel<false>", lambda g: g > 1000000)}
