@@ -228,14 +228,19 @@ int fb_qnet_get_adam_state(fb_qnet_t h, float *m, float *v, float *beta_pows_hos
 int fb_qnet_set_adam_state(fb_qnet_t h, const float *m, const float *v, const float *beta_pows_host);
 int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float eps);
 /* Arithmetic of the forward-only path on >= 256 states (fb_qnet_forward / fb_qnet_act / fb_qnet_act_nib):
- *   FB_DTYPE_F32  (default) fp32-equivalent: every fp32 product as three fp16 MFMA products of two planes (x = h + l/4096)
+ *   FB_DTYPE_F32  (default) fp32-equivalent: every fp32 product as three fp16 MFMA products of two planes (x = h + l/4096).  The
+ *                 pair carries x to 2^-24 relative for 2^-14 <= |x| < 65504 (fp16's normal range): weights and activations of this
+ *                 network live there; gradient operands (1e-6 .. 1e-9 in the reference's regime) are brought there by an exact
+ *                 power-of-two pre-scale taken from the operand block's maximum, folded back in the epilogue (csrc/fb_qnet.hip
+ *                 pow2_scale; tests/test_gpu_qnet.py::test_train_step_gradients_in_the_reference_regime)
  *   FB_DTYPE_BF16 plain bf16 inference (config 3 of BASELINE.json: "bf16"): activations and weights rounded to
  *                 bf16, fp32 accumulation.  Training and batches < 256 always compute in fp32. */
 #define FB_DTYPE_F32 0
 #define FB_DTYPE_BF16 1
 int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype);
 /* Arithmetic of fb_qnet_train_step (BASELINE.json configs[2]: "bf16"):
- *   FB_DTYPE_F32  (default) fp32: small batches on the fp32-input matrix instruction, >= 256 states per slice on two-plane fp16
+ *   FB_DTYPE_F32  (default) fp32: the fc1 GEMMs of small batches on the fp32-input matrix instruction, everything else on two-plane fp16
+ *                 (as above, gradient operands pre-scaled)
  *   FB_DTYPE_BF16 bf16 training: every GEMM operand (activations, weights, incoming gradients; conv1's u8 input is exact anyway)
  *                 is rounded to bf16, products accumulate in fp32, the master weights and both Adam slots stay fp32.  Gradients
  *                 then agree with fp32 ones to a few per cent per tensor (tests/test_gpu_configs.py states the bound). */
@@ -288,7 +293,19 @@ const char *fb_qnet_kernel_name(int kernel);
  * Memory.batch_update in the same call (fb_replay_push, fb_replay_sample, fb_train_from_replay, fb_replay_update_priorities: no riders).
  * All pointers [dev], caller owned; nib is the buffer given to fb_env_set_nib_buffer.  train = 0 stops after the
  * store (the reference's OBSERVE phase).  flat_grad as in fb_qnet_train_step (data parallel: all-reduce it, then
- * fb_qnet_apply_adam). */
+ * fb_qnet_apply_adam).
+ *
+ * hipGraph capture.  State that decides what a launch does lives on the device (parameter / plane versions, Adam's step counter, the
+ * sampler's generator, SumTree pointer / size, beta), so a captured call replays correctly -- with ONE exception: the replay memory's
+ * push counter also has a host-side mirror (it is passed by value into the launches that address the frame ring), so a captured
+ * launch that pushes or addresses the ring is only valid while the memory holds the number of pushes it held at capture time.
+ *   capturable, replayable any number of times:  fb_qnet_forward / _act / _act_nib, fb_qnet_train_step, fb_qnet_apply_adam,
+ *       fb_qnet_sync_target, fb_env_step, fb_replay_sample, fb_replay_update_priorities, and -- on a memory that is NOT pushed to
+ *       between capture and the last replay -- fb_replay_gather, fb_train_from_replay and fb_train_steps (what bench.py's
+ *       train-only leg does: fb_train_steps(10) in one graph)
+ *   NOT capturable for replay:  fb_replay_push / _push_sample, fb_vec_step, fb_vec_step_dp (they advance the push counter: a replay
+ *       would write the same ring slot again and sample a memory of the captured size); synchronous calls (get / set state, seeds,
+ *       hyper-parameters, checkpoints) synchronise the device and must stay outside a capture. */
 typedef struct {
     uint8_t *nib;                                   /* u8[N,FB_NIB_STRIDE] */
     uint8_t *actions;                               /* u8[N] out */

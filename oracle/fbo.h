@@ -110,6 +110,7 @@ size_t fbo_qnet_nparams(fbo_qcfg c);
 size_t fbo_qnet_act_floats(fbo_qcfg c);
 void fbo_qnet_forward(const float *params, fbo_qcfg c, const uint8_t *states, int B, float *q, float *acts);
 float fbo_qnet_last_margin(void);     /* min |ReLU input| / pool win margin of the last forward (same thread) */
+float fbo_qnet_last_margin_nonzero(void);   /* the same, exact ties / zeros (pool windows over identical pixels) left out */
 void fbo_qnet_backward(const float *params, fbo_qcfg c, const uint8_t *states, int B,
                        const float *acts, const float *dq, float *grads);
 void fbo_adam_step(float *p, float *m, float *v, const float *g, size_t n, float lr, float b1,

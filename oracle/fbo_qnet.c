@@ -32,9 +32,16 @@
 /* Smallest distance of any ReLU input from 0 / of any pool winner from its runner-up seen by the last
  * fbo_qnet_forward: gradient checks through ReLUs are only meaningful away from the kinks, the tests use
  * this to pick data with a safe margin. */
-static __thread float g_margin = 1e30f;
+static __thread float g_margin = 1e30f, g_margin_nz = 1e30f;
 float fbo_qnet_last_margin(void) { return g_margin; }
-static inline void margin(float v) { float a = v < 0 ? -v : v; if (a < g_margin) g_margin = a; }
+/* the same without the EXACT ties / zeros: game frames have pool windows over identical pixels (four equal conv outputs: margin 0, the
+ * same first-maximum in every arithmetic, and equal contributions whichever position wins), which random frames never have */
+float fbo_qnet_last_margin_nonzero(void) { return g_margin_nz; }
+static inline void margin(float v) {
+    float a = v < 0 ? -v : v;
+    if (a < g_margin) g_margin = a;
+    if (a > 0 && a < g_margin_nz) g_margin_nz = a;
+}
 
 enum { O_W1 = 0, O_B1 = 8192, O_W2 = 8224, O_B2 = 40992, O_W3 = 41056, O_B3 = 77920, O_WF1 = 77984 };
 
@@ -115,7 +122,7 @@ void fbo_qnet_forward(const float *P, fbo_qcfg c, const uint8_t *states, int B, 
     size_t AF = fbo_qnet_act_floats(c);
     float *x = (float *)malloc(sizeof(float) * 25600);
     float *tmp = acts ? NULL : (float *)malloc(sizeof(float) * AF);
-    g_margin = 1e30f;
+    g_margin = 1e30f; g_margin_nz = 1e30f;
     for (int b = 0; b < B; b++) {
         float *a = acts ? acts + (size_t)b * AF : tmp;
         const uint8_t *s = states + (size_t)b * 25600;

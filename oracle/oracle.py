@@ -80,6 +80,7 @@ def lib():
         L.fbo_qnet_forward.argtypes = [C.c_void_p, QCfg, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.fbo_qnet_backward.argtypes = [C.c_void_p, QCfg, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fbo_qnet_last_margin.restype = C.c_float
+        L.fbo_qnet_last_margin_nonzero.restype = C.c_float
         L.fbo_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_void_p] * 2
         L.fbo_dqn_loss.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 4
         L.fbo_trunc_normal_init.argtypes = [C.c_void_p, QCfg, C.c_uint32, C.c_uint32]
@@ -294,9 +295,10 @@ def dqn_loss(kind, q, q_next_sel, action, reward, terminal, isw=None, gamma=0.99
     return y, loss.value, ae, dq
 
 
-def last_margin():
-    """Smallest |ReLU input| and pool win margin seen by the last forward() call."""
-    return lib().fbo_qnet_last_margin()
+def last_margin(nonzero=False):
+    """Smallest |ReLU input| and pool win margin seen by the last forward() call (nonzero: exact ties / zeros left out -- game
+    frames have pool windows over identical pixels)."""
+    return lib().fbo_qnet_last_margin_nonzero() if nonzero else lib().fbo_qnet_last_margin()
 
 
 class Adam:

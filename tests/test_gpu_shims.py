@@ -253,7 +253,7 @@ def test_nibble_state_equals_current_state_and_act_nib_is_bit_identical(torch_cu
         rep.push(env.frame_bits, acts, env.reward, env.terminal)
 
 
-@pytest.mark.parametrize("N,steps", [(256, 40), (2304, 24)])
+@pytest.mark.parametrize("N,steps", [(256, 40), (1024, 30), (2304, 24)])      # 1024 envs / batch 32: the bench's own workload
 def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
     """fb_vec_step (one host call per step; head, random.sample and the Memory append riding in the env launch) ==
     act_nib -> frame_step -> push_sample -> gather -> train_step: same actions, env states, sampled indices and
@@ -336,6 +336,53 @@ def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B, dt
     assert same(m1, m2) and same(v1, v2)
     with pytest.raises(Exception):
         train_from_replay(rep, n2, algo, torch.zeros(257, dtype=torch.int64, device="cuda"))
+
+
+@pytest.mark.parametrize("algo,dueling,B", [("dqn", False, 32), ("double", True, 32), ("per", False, 32)])
+def test_ring_fed_train_step_gradients_match_oracle(torch_cuda, oracle, algo, dueling, B):
+    """The ring-fed train step (fb_train_from_replay: conv trunk straight from the 1-bit frame ring -- what fb_vec_step and
+    fb_train_steps launch) against the ORACLE directly, not through its equality with gather + train_step: the oracle gets the u8
+    states the gather kernel expands from the same ring (themselves tied to the DequeModel in test_gpu_replay.py), the device never
+    builds them.  Targets within 1e-4, every gradient tensor within 2e-3 of the fp64-accumulating oracle."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, train_from_replay
+    from tests.test_gpu_qnet import oracle_train_grads, trained_like_params
+    N = 64
+    env, rep = VecGameState(N, seed=11), VecReplay(4000, N)
+    env.observe(); rep.reset(env.frame_bits)
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        acts = torch.from_numpy((rng.random(N) < 0.12).astype(np.uint8)).cuda()
+        env.frame_step(acts, want_u8=False)
+        rep.push(env.frame_bits, acts, env.reward, env.terminal)
+    cfg = oracle.qcfg(512, 2, dueling)
+    p_on, p_tg = trained_like_params(oracle, cfg, 1), trained_like_params(oracle, cfg, 2)
+    net = QNet(2, 512, "dueling" if dueling else "plain", max_batch=B)
+    net.load_params(p_on, 0); net.load_params(p_tg, 1)
+    size = len(rep)
+    for attempt in range(60):                            # kink-free minibatch (see test_train_step_gradients_match_oracle)
+        idx = torch.from_numpy(rng.integers(0, size, B)).cuda()
+        s, a, r, s2, t = (x.cpu().numpy() for x in rep.gather(idx))
+        oracle.forward(p_on, cfg, s)
+        if oracle.last_margin(nonzero=True) > 2e-5:      # (game frames: pool windows over identical pixels tie exactly, in every arithmetic)
+            break
+    else:
+        pytest.fail("no kink-free batch found")
+    isw = rng.random(B).astype(np.float32) if algo == "per" else None
+    iswd = None if isw is None else torch.from_numpy(isw).cuda()
+    grad = torch.zeros(net.n_params, dtype=torch.float32, device="cuda")
+    out = train_from_replay(rep, net, algo, idx, flat_grad=grad, isw=iswd, want_abs_err=True)
+    loss, ae = out[0], out[4]
+    y0, loss0, ae0, g0 = oracle_train_grads(oracle, cfg, p_on, p_tg, algo, s, a, r, s2, t, isw)
+    np.testing.assert_allclose(loss.item(), loss0, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ae.cpu().numpy(), ae0, rtol=0, atol=2e-4)
+    g = grad.cpu().numpy()
+    bounds = [0, 8192, 8224, 40992, 41056, 77920, 77984, 77984 + 1600 * 512, 77984 + 1600 * 512 + 512, net.n_params]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        scale = np.abs(g0[lo:hi]).max()
+        assert scale > 0
+        np.testing.assert_allclose(g[lo:hi], g0[lo:hi], rtol=2e-3, atol=2e-5 * scale, err_msg=f"params[{lo}:{hi}]")
+    assert np.array_equal(net.store_params().cpu().numpy(), p_on)          # gradient-only mode
 
 
 @pytest.mark.parametrize("N,steps,algo", [(256, 40, "dqn"), (2304, 24, "nature")])
