@@ -66,7 +66,11 @@ class BrainDQN:
     INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY = INITIAL_EPSILON, FINAL_EPSILON, REPLAY_MEMORY
 
     def __init__(self, actionNum, gameName, backend=None, fc_width=512, verbose=True, seed=None,
-                 save_root="./saved_parameters", logs_root="./logs_", record_logs=True, save_replay=False):
+                 save_root="./saved_parameters", logs_root="./logs_", record_logs=True, save_replay=False, checkpoint_format="npz"):
+        # checkpoint_format: "npz" (flat fp32 vectors, the default) or "tf" -- the reference's own format, a TensorFlow Saver-V2 bundle
+        # (bird-<timeStep>.index / .data-00000-of-00001 with the reference's variable names, tf_bundle.py) that `saver.restore` of
+        # the reference reads.  Loading recognises both, whichever the `checkpoint` file names.
+        self.checkpoint_format = checkpoint_format
         # save_replay: also checkpoint what the reference forgets (:176-192) -- the replay memory, onlineTimeStep, the current
         # frame stack and the `random` / np.random generator states -- so that a resumed run does not observe again and continues
         # the sampled-index stream bit for bit.  Default False = the reference's behaviour.
@@ -125,13 +129,22 @@ class BrainDQN:
                 print("Could not find old network weights")
             return False
         with open(marker) as f:
-            ckpt = os.path.join(self.save_path, f.read().strip())
-        z = np.load(ckpt)
+            first = f.readline().strip()
+        tf_style = first.startswith("model_checkpoint_path:")        # what tf.train.Saver writes (reference :178-181)
+        ckpt = os.path.join(self.save_path, os.path.basename(first.split(":", 1)[1].strip().strip('"')) if tf_style else first)
+        if tf_style or os.path.exists(ckpt + ".index"):
+            from . import tf_bundle
+            z = tf_bundle.load_flat(ckpt)                              # the reference's own checkpoint format
+            if z["target"] is None:                                    # single-net graph (BrainDQN): the target copy is the net itself
+                z["target"] = z["online"]
+        else:
+            z = np.load(ckpt)
         if z["online"].size != self.net.n_params:
             raise ValueError(f"{ckpt} holds {z['online'].size} parameters, this network has {self.net.n_params}")
         self.net.load_params(z["online"], 0)
         self.net.load_params(z["target"], 1)
-        self.net.set_adam_state(self._be.dev(z["adam_m"]), self._be.dev(z["adam_v"]), z["beta_pows"])
+        if z["adam_m"] is not None:
+            self.net.set_adam_state(self._be.dev(z["adam_m"]), self._be.dev(z["adam_v"]), z["beta_pows"])
         if self.verbose:
             print("Successfully loaded:", ckpt)
         if os.path.exists(self.saved_parameters_file_path) and os.path.getsize(self.saved_parameters_file_path) > 0:
@@ -139,7 +152,7 @@ class BrainDQN:
                 self.gameTimes = _load_scalar(f)
                 self.timeStep = _load_scalar(f)
                 self.epsilon = _load_scalar(f)
-        extra = ckpt[:-4] + "-replay.npz"
+        extra = (ckpt[:-4] if ckpt.endswith(".npz") else ckpt) + "-replay.npz"
         if self.save_replay and os.path.exists(extra) and hasattr(self.replayMemory, "load_state_blob"):
             e = np.load(extra)
             self.replayMemory.load_state_blob(e["replay"])
@@ -155,13 +168,25 @@ class BrainDQN:
     def save_checkpoint(self):
         """reference :227-233 (saver.save + three pickle.dump calls)."""
         os.makedirs(self.save_path, exist_ok=True)
-        name = f"{self.gameName}-{self.timeStep}.npz"
         m, v, pows = self.net.adam_state()
-        np.savez(os.path.join(self.save_path, name), online=self._be.host(self.net.store_params(0)),
-                 target=self._be.host(self.net.store_params(1)), adam_m=self._be.host(m), adam_v=self._be.host(v),
-                 beta_pows=np.asarray(pows, np.float32))
-        with open(os.path.join(self.save_path, "checkpoint"), "w") as f:
-            f.write(name + "\n")
+        if self.checkpoint_format == "tf":
+            # saver.save(sess, SAVE_PATH + gameName, global_step=timeStep): the bundle + the `checkpoint` state file (no .meta: there is
+            # no graph).  One net (BrainDQN's names) unless the algorithm keeps a target net (the eval_net / target_net scopes)
+            from . import tf_bundle
+            name = f"{self.gameName}-{self.timeStep}"
+            two = getattr(self, "ALGO", "dqn") != "dqn"
+            tf_bundle.save_flat(os.path.join(self.save_path, name), self._be.host(self.net.store_params(0)),
+                                self._be.host(self.net.store_params(1)) if two else None, self._be.host(m), self._be.host(v), pows)
+            with open(os.path.join(self.save_path, "checkpoint"), "w") as f:
+                f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
+            name += ".npz"                                             # (the replay side file below keeps its name scheme)
+        else:
+            name = f"{self.gameName}-{self.timeStep}.npz"
+            np.savez(os.path.join(self.save_path, name), online=self._be.host(self.net.store_params(0)),
+                     target=self._be.host(self.net.store_params(1)), adam_m=self._be.host(m), adam_v=self._be.host(v),
+                     beta_pows=np.asarray(pows, np.float32))
+            with open(os.path.join(self.save_path, "checkpoint"), "w") as f:
+                f.write(name + "\n")
         with open(self.saved_parameters_file_path, 'wb') as f:
             pickle.dump(self.gameTimes, f)
             pickle.dump(self.timeStep, f)
