@@ -33,8 +33,10 @@ def model_class(name):
     from .BrainDoubleDQN import BrainDoubleDQN
     from .BrainDuelingDQN_CC import BrainDuelingDQN
     from .BrainPrioritizedReplyDQN import BrainPrioritizedReplyDQN
+    from .BrainActorCritic import BrainDQNActorCritic
+    from .BrainPolicyGradient import BrainPolicyGradient
     table = {"dqn": BrainDQN, "ddqn": BrainDoubleDQN, "dqnnature": BrainDQNNature, "duelingdqn": BrainDuelingDQN,
-             "prioritydqn": BrainPrioritizedReplyDQN}
+             "prioritydqn": BrainPrioritizedReplyDQN, "actorcritic": BrainDQNActorCritic, "policygradient": BrainPolicyGradient}
     if name not in table:
         print("invalid model!")
         raise SystemExit(1)
@@ -72,6 +74,8 @@ def main():
         from . import dist as fdist
         from .vecbrain import VecBrain
         rank, _, world = fdist.init()
+        if args.model in ("actorcritic", "policygradient"):
+            raise SystemExit("--vec runs the DQN family; the actor-critic / policy-gradient agents are single-env (as in the reference)")
         algo = {"dqn": "dqn", "ddqn": "nature", "dqnnature": "nature", "duelingdqn": "nature", "prioritydqn": "per"}[args.model]
         vb = VecBrain(args.vec, algo=algo, rank=rank, world=world)
         vb.run(args.steps or 1000, log_every=0 if (args.quiet or rank) else 100)

@@ -16,7 +16,7 @@ REPLAY_UNIFORM, REPLAY_PER = 0, 1
 RNG_CPYTHON, RNG_PHILOX, RNG_NUMPY = 0, 1, 2
 ARCH_PLAIN, ARCH_DUELING = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
-ALGO_DQN, ALGO_NATURE, ALGO_DOUBLE, ALGO_PER = 0, 1, 2, 3
+ALGO_DQN, ALGO_NATURE, ALGO_DOUBLE, ALGO_PER, ALGO_PG = 0, 1, 2, 3, 4
 DTYPE_F32, DTYPE_BF16 = 0, 1
 PER_EXACT, PER_FAST = 0, 1
 NIB_PITCH, NIB_ROWS, NIB_STRIDE = 44, 84, 3712       # include/fbdqn.h FB_NIB_*

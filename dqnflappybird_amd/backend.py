@@ -30,3 +30,7 @@ class HipBackend:
     @staticmethod
     def host(t):
         return t.cpu().numpy()
+
+    @staticmethod
+    def zeros(n):
+        return torch.zeros(n, dtype=torch.float32, device="cuda")

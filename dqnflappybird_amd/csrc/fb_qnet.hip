@@ -1689,13 +1689,30 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
         const float d = y - qe;                                      // q_eval = reduce_sum(Q * onehot)
         const float scale = L.algo == FB_ALGO_DQN ? 2.f : 2.f / (float)B;     // sum vs mean
         const float gq = -scale * isw * d;                           // dLoss/dQ[b][a_b]
+        // FB_ALGO_PG (BrainPolicyGradient.py:96-100; the actor of BrainActorCritic.py:96-100): Q(s) are LOGITS; loss = mean over
+        // gamma (= the number of samples of the whole batch this chunk belongs to) of softmax_cross_entropy(logits, action) x weight,
+        // the weight arriving where the rewards do.  dLoss/dlogit[c] = (softmax[c] - onehot[c]) x weight / N; these sum to 0 over c,
+        // so a dueling head's V receives nothing and its advantages the same values.
+        const bool pg = L.algo == FB_ALGO_PG;
+        float pgp[AT], pgl;
+        {
+            float mx = qsv[0], se = 0.f;
+#pragma unroll
+            for (int c = 1; c < AT; c++) mx = c < A ? fmaxf(mx, qsv[c]) : mx;
+#pragma unroll
+            for (int c = 0; c < AT; c++) { pgp[c] = c < A ? expf(qsv[c] - mx) : 0.f; se += pgp[c]; }
+#pragma unroll
+            for (int c = 0; c < AT; c++) pgp[c] /= se;
+            pgl = logf(se) - (qe - mx);                              // -log softmax[a_b]
+        }
+        const float pgw = rf / (float)L.gamma;
         if (j == 0 && b < B) {
-            lterm[b] = isw * d * d;
+            lterm[b] = pg ? pgl * pgw : isw * d * d;
             if (lead && L.abs_err) L.abs_err[b] = fabsf(d);
             if (lead && L.y_out) L.y_out[b] = y;
-            dv[b] = L.dueling ? gq : 0.f;
+            dv[b] = L.dueling && !pg ? gq : 0.f;
 #pragma unroll
-            for (int c = 0; c < AT; c++) dadv[b][c] = (c == a_b ? gq : 0.f) - (L.dueling ? gq / (float)A : 0.f);
+            for (int c = 0; c < AT; c++) dadv[b][c] = pg ? (pgp[c] - (c == a_b ? 1.f : 0.f)) * pgw : (c == a_b ? gq : 0.f) - (L.dueling ? gq / (float)A : 0.f);
             if (AT == 2) { dadv2[2 * b] = dadv[b][0]; dadv2[2 * b + 1] = dadv[b][1]; }
         }
     }
@@ -1709,7 +1726,7 @@ __device__ __forceinline__ void fc1_bwd2_body(const Bw1Args &L, float *smem) {
     if (lead && tid == 0) {
         float sum = 0.f;
         for (int b = 0; b < B; b++) sum += lterm[b];
-        *L.loss = L.algo == FB_ALGO_DQN ? sum : sum / (float)B;
+        *L.loss = L.algo == FB_ALGO_DQN || L.algo == FB_ALGO_PG ? sum : sum / (float)B;       // (PG: the 1 / N is in every term)
         if (L.tick && L.adam->ticks == L.adam->applies) {            // Adam step counter for the update that follows (see AdamDev)
             AdamDev &ad = *L.adam;
             ad.alpha = ad.lr * sqrtf(1.f - ad.b2pow) / (1.f - ad.b1pow);
@@ -3301,14 +3318,15 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
                       const uint8_t *t, const float *isw, double gamma, float *loss, float *abs_err, float *q_target,
                       float *flat_grad, Plan *out, const FbRingSrc *ring = nullptr) {
     FB_REQUIRE(h && a && r && t && loss && (ring || (s && s2)), "fb_qnet_train_step: NULL argument");
-    FB_REQUIRE(algo >= 0 && algo <= 3, "fb_qnet_train_step: unknown algo %d", algo);
+    FB_REQUIRE(algo >= 0 && algo <= FB_ALGO_PG, "fb_qnet_train_step: unknown algo %d", algo);
     FB_REQUIRE(B >= 1 && B <= h->max_batch && B <= MAXTB, "fb_qnet_train_step: batch %d exceeds min(max_batch, %d)", B, MAXTB);
+    FB_REQUIRE(algo != FB_ALGO_PG || (B <= 128 && !ring && gamma >= (double)B), "fb_qnet_train_step: FB_ALGO_PG takes chunks of <= 128 gathered states and gamma = the whole batch's sample count (>= %d)", B);
     FB_REQUIRE(algo != FB_ALGO_PER || isw, "fb_qnet_train_step: PER needs isw");
     Plan p; memset(&p, 0, sizeof(p));
     // forward: s through the online net, s' through the net(s) the algorithm asks for
     p.ns = 2;
     p.sl.s[0] = Slice{h->params[0], s, 0, B, h->w1s[0], 0};
-    if (algo == FB_ALGO_DQN) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0], 1};               // BrainDQN.py:205 (same net)
+    if (algo == FB_ALGO_DQN || algo == FB_ALGO_PG) p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0], 1};               // BrainDQN.py:205 (same net); PG: s2 is forwarded and ignored
     else if (algo == FB_ALGO_DOUBLE) { p.sl.s[1] = Slice{h->params[0], s2, B, B, h->w1s[0], 1}; p.sl.s[2] = Slice{h->params[1], s2, 2 * B, B, h->w1s[1], 1}; p.ns = 3; }
     else p.sl.s[1] = Slice{h->params[1], s2, B, B, h->w1s[1], 1};                                // target net
     p.sl.rb = h->nsplit_train == 1;

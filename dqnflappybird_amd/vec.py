@@ -239,7 +239,7 @@ class VecReplay:
         return tree, ptr_.value, size.value, beta.value
 
 
-ALGOS = {"dqn": L.ALGO_DQN, "nature": L.ALGO_NATURE, "double": L.ALGO_DOUBLE, "per": L.ALGO_PER}
+ALGOS = {"dqn": L.ALGO_DQN, "nature": L.ALGO_NATURE, "double": L.ALGO_DOUBLE, "per": L.ALGO_PER, "pg": L.ALGO_PG}
 
 
 class QNet:
@@ -362,6 +362,17 @@ class QNet:
                                            L.ptr(r), L.ptr(s2), L.ptr(t), L.ptr(isw), float(gamma), L.ptr(loss), L.ptr(ae),
                                            L.ptr(y), L.ptr(flat_grad), L.current_stream()), "fb_qnet_train_step")
         return loss, ae, y
+
+    def pg_step(self, states, actions, weights, n_total=None, flat_grad=None):
+        """One policy-gradient step (FB_ALGO_PG) on <= 128 states: loss = sum over them of softmax_cross_entropy(logits, action) x
+        weight / n_total (n_total defaults to the chunk size = a plain mean).  flat_grad=None applies Adam; a float32[n_params] tensor
+        receives the chunk's gradient instead (episodes longer than 128: add the chunks' gradients, then apply_adam once).
+        -> loss f32[1] (device)."""
+        B = states.shape[0]
+        zeros = self._get(f"pgt{B}", (B,), torch.uint8)
+        zeros.zero_()
+        loss, _, _ = self.train_step("pg", states, actions, weights, states, zeros, gamma=float(n_total or B), flat_grad=flat_grad, want_aux=False)
+        return loss
 
     def apply_adam(self, flat_grad):
         _dev_check(flat_grad)

@@ -215,6 +215,12 @@ typedef struct fb_qnet *fb_qnet_t;
 #define FB_ALGO_NATURE 1         /* BrainDQNNature: frozen target net, loss = mean */
 #define FB_ALGO_DOUBLE 2         /* BrainDoubleDQN.trainQNetwork: argmax online, value target, mean */
 #define FB_ALGO_PER 3            /* BrainPrioritizedReplyDQN: target net, mean(ISW * sq), abs_errors */
+/* Policy gradient (BrainPolicyGradient.py:96-100; the actor of BrainActorCritic.py:96-100): the net's outputs are LOGITS,
+ * loss = mean over N samples of softmax_cross_entropy(logits, action) x weight.  In fb_qnet_train_step: r = the weights (what the
+ * reference feeds as tf_rewards / td_error), gamma = N as a double -- a batch larger than 128 (one whole episode) goes in chunks of
+ * <= 128 that export their gradient (flat_grad), the caller adds them up and calls fb_qnet_apply_adam once; s2 / t are ignored (pass
+ * s / zeros), abs_err / q_target are not meaningful; loss = this chunk's share of the mean.  Not available through fb_vec_step. */
+#define FB_ALGO_PG 4
 
 int fb_qnet_create(int arch, int fc_width, int n_actions, int max_batch, fb_qnet_t *out);
 int fb_qnet_destroy(fb_qnet_t h);

@@ -119,6 +119,8 @@ void fbo_adam_step(float *p, float *m, float *v, const float *g, size_t n, float
 void fbo_dqn_loss(int kind, int B, int A, const float *q, const float *q_next_sel, const uint8_t *action,
                   const float *reward, const uint8_t *terminal, const float *isw, double gamma,
                   float *y, float *loss, float *abs_err, float *dq);
+/* policy-gradient loss (BrainPolicyGradient.py:96-100): mean over n_total of softmax cross-entropy x weight; this chunk's share */
+void fbo_pg_loss(int B, int A, const float *q, const uint8_t *action, const float *w, double n_total, float *loss, float *dq);
 void fbo_trunc_normal_init(float *params, fbo_qcfg c, uint32_t seed_lo, uint32_t seed_hi);
 
 /* ---------------------------------------------------------------- single-env loop (CPU baseline) */

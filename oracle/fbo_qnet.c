@@ -288,6 +288,24 @@ void fbo_dqn_loss(int kind, int B, int A, const float *q, const float *q_next_se
     *loss = (float)(kind == 0 ? L : L / B);
 }
 
+/* Policy-gradient loss of BrainPolicyGradient.py:96-100 (and the actor of BrainActorCritic.py:96-100):
+ * neg_log_prob = softmax_cross_entropy_with_logits(logits = Q, labels = onehot(action)); loss = mean over n_total of neg_log_prob x w.
+ * q holds the logits of B of those n_total samples; loss / dq are this chunk's share. */
+void fbo_pg_loss(int B, int A, const float *q, const uint8_t *action, const float *w, double n_total, float *loss, float *dq) {
+    double L = 0;
+    for (int b = 0; b < B; b++) {
+        const float *z = q + (size_t)b * A;
+        double mx = z[0], se = 0;
+        for (int a = 1; a < A; a++) if (z[a] > mx) mx = z[a];
+        for (int a = 0; a < A; a++) se += exp((double)z[a] - mx);
+        const double nlp = log(se) - ((double)z[action[b]] - mx);
+        L += nlp * (double)w[b] / n_total;
+        for (int a = 0; a < A; a++)
+            dq[(size_t)b * A + a] = (float)((exp((double)z[a] - mx) / se - (a == action[b] ? 1.0 : 0.0)) * (double)w[b] / n_total);
+    }
+    *loss = (float)L;
+}
+
 /* tf.truncated_normal(stddev=0.01): N(0, 0.01) re-drawn beyond 2 sigma; biases 0.01
  * (BrainDQN.py:123-152).  Our own Philox stream 4 + Box-Muller: the reference
  * is unseeded, so there is no draw sequence to match -- only the distribution. */

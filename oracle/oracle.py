@@ -84,6 +84,7 @@ def lib():
         L.fbo_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_void_p] * 2
         L.fbo_dqn_loss.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 4
         L.fbo_trunc_normal_init.argtypes = [C.c_void_p, QCfg, C.c_uint32, C.c_uint32]
+        L.fbo_pg_loss.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.fbo_reference_loop.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.fbo_philox4x32.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
         with open(ASSET_BLOB, "rb") as f:
@@ -293,6 +294,18 @@ def dqn_loss(kind, q, q_next_sel, action, reward, terminal, isw=None, gamma=0.99
     lib().fbo_dqn_loss(kind, B, A, _p(q), _p(qn), _p(action), _p(reward), _p(terminal), _p(isw), gamma,
                        _p(y), C.byref(loss), _p(ae), _p(dq))
     return y, loss.value, ae, dq
+
+
+def pg_loss(q, action, w, n_total=None):
+    """BrainPolicyGradient.py:96-100: -> (loss, dq) of mean(softmax_cross_entropy(q, action) * w) over n_total (default: len(q))."""
+    B, A = q.shape
+    q = np.ascontiguousarray(q, np.float32)
+    action = np.ascontiguousarray(action, np.uint8)
+    w = np.ascontiguousarray(w, np.float32)
+    dq = np.empty((B, A), np.float32)
+    loss = C.c_float()
+    lib().fbo_pg_loss(B, A, _p(q), _p(action), _p(w), float(n_total or B), C.byref(loss), _p(dq))
+    return loss.value, dq
 
 
 def last_margin(nonzero=False):

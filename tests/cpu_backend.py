@@ -43,6 +43,17 @@ class CpuNet:
             flat_grad[...] = g
         return np.float32(loss), ae, y
 
+    def pg_step(self, states, actions, weights, n_total=None, flat_grad=None):
+        q, acts = o.forward(self.p[0], self.cfg, states, keep=True)
+        loss, dq = o.pg_loss(q, actions, weights, n_total)
+        g = o.backward(self.p[0], self.cfg, states, acts, dq)
+        self.train_calls.append("pg")
+        if flat_grad is None:
+            self.opt.step(self.p[0], g)
+        else:
+            flat_grad[...] = g
+        return np.float32(loss)
+
     def apply_adam(self, g):
         self.opt.step(self.p[0], g)
 
@@ -123,6 +134,10 @@ class CpuBackend:
     @staticmethod
     def host(t):
         return np.asarray(t)
+
+    @staticmethod
+    def zeros(n):
+        return np.zeros(n, np.float32)
 
 
 # --------------------------------------------------------------------------------------------------------------------
