@@ -184,95 +184,189 @@ __device__ __forceinline__ int node_depth(long long node) {          // root = 0
 // ancestor of leaf ti (depth D) at depth d <= D
 __device__ __forceinline__ long long anc(long long ti, int D, int d) { return ((ti + 1) >> (D - d)) - 1; }
 
-// Exact SumTree.update for a list of (tree_idx, p) applied IN ORDER (BrainPrioritizedReplyDQN.py:62-68),
-// on one wave: lane d owns the nodes at depth d.  The values of all touched nodes are first loaded
-// side by side (no dependent global latency), then the wave walks the list in lockstep:
-// change_j = p_j - leaf_j (the leaf's lane), every lane above adds change_j to its ancestor.  A node
-// touched by several list entries takes the value its previous occurrence left (prev[][]), which is
-// exactly the read-modify-write order of the reference's loop -- so the tree bytes are the reference's.
-// MONOTONE: the caller guarantees consecutive leaves of one depth without ring wrap (Memory.store),
-// so equal nodes are adjacent in the list and the duplicate search is one comparison.
-struct UpdScratch {
-    double val[MAXB][MAXH];          // value of node (j, depth) after step j
-    short prev[MAXB][MAXH];          // latest j' < j with the same node at that depth, or -1
-    long long ti[MAXB];
-    double p[MAXB];
+// Exact SumTree.update for a list of (tree_idx, p) applied IN ORDER (BrainPrioritizedReplyDQN.py:62-68).
+// The values of all touched nodes are first loaded side by side (no dependent global latency), then ONE wave walks the list in
+// lockstep, lane d owning the nodes at depth d: change_j = p_j - leaf_j (the leaf's lane), every lane above adds change_j to its
+// ancestor.  A node touched by several list entries takes the value its previous occurrence left (prev[][]), which is exactly the
+// read-modify-write order of the reference's loop -- so the tree bytes are the reference's.
+// What surrounds the walk is organised around ONE table (round 3; it was an O(n) ancestor search per (entry, depth), a depth-serial
+// write-back and 21 barrier-separated passes over global memory for the max / min heaps: 27.5 us at n = 32, depth 21):
+//   lcd[j][q] = depth of the lowest common ancestor of the leaves of entries j and q (the heap index + 1 IS the root-to-node path:
+//   align the two to one depth, xor, count leading zeros).  From row j, in one pass over q:
+//     prev[j][d]   = the largest q < j with lcd >= d   (the previous occurrence of j's depth-d ancestor: the duplicate link)
+//     last bit d   = no q > j with lcd >= d            (j writes that node back: the last occurrence wins, like the reference's loop)
+//     sib[j][d]    = some q with lcd == d exactly      (j's depth-(d+1) SIBLING subtree is touched too: its max / min come from q)
+//   and the heaps are finished in shared memory: thread j carries (max, min) of its path node from its leaf to the root, one level per
+//   step, taking the sibling's pair from the sibling entry's LDS word when that subtree was touched and from a value pre-loaded into
+//   registers otherwise (all 2 x 22 loads of a thread in flight together); entries sharing a node compute and store the same pair.
+#ifndef PU_EXIT
+#define PU_EXIT 0                    // ablation: return behind phase k of per_apply_updates (tools/time_per.py against -DPU_EXIT=k builds)
+#endif
+struct UpdLayout {                   // byte offsets inside the dynamic LDS block, for a list of n entries
+    int val, prev, sib, ti, p, lcd, last, rep, mask, cur, bytes;
+    __host__ __device__ explicit UpdLayout(int n) {
+        int o = 0;
+        val = o; o += n * MAXH * 8;
+        ti = o; o += n * 8;
+        p = o; o += n * 8;
+        cur = o; o += 4 * n * 8;
+        prev = o; o += n * MAXH * 2;
+        sib = o; o += n * MAXH * 2;
+        last = o; o += n * 4;
+        rep = o; o += n * 4;
+        mask = o; o += 16;
+        lcd = o; o += n * n;
+        bytes = (o + 15) & ~15;
+    }
 };
 
-template <bool MONOTONE>
-__device__ void per_apply_updates(const ReplayParams &P, UpdScratch &S, int n, int tid, int nthreads) {
-    // 1) preload + duplicate links, all threads
+__device__ void per_apply_updates(const ReplayParams &P, unsigned char *smem, int n, int tid, int nthreads) {
+    const UpdLayout Lo(n);
+    double (*val)[MAXH] = reinterpret_cast<double (*)[MAXH]>(smem + Lo.val);
+    short (*prev)[MAXH] = reinterpret_cast<short (*)[MAXH]>(smem + Lo.prev);
+    short (*sib)[MAXH] = reinterpret_cast<short (*)[MAXH]>(smem + Lo.sib);
+    const long long *ti_s = reinterpret_cast<const long long *>(smem + Lo.ti);
+    const double *p_s = reinterpret_cast<const double *>(smem + Lo.p);
+    unsigned char *lcd = smem + Lo.lcd;
+    unsigned *lastm = reinterpret_cast<unsigned *>(smem + Lo.last);
+    int *rep_s = reinterpret_cast<int *>(smem + Lo.rep);                 // the last entry with the same leaf (its p is the leaf's final value)
+    unsigned *sibmask = reinterpret_cast<unsigned *>(smem + Lo.mask);    // bit d: some entry's depth-(d + 1) sibling subtree is touched
+    double *cur = reinterpret_cast<double *>(smem + Lo.cur);             // [parity][max | min][n]
+    if (tid == 0) *sibmask = 0u;
+    // 0) the common-ancestor depths of all pairs
+    for (int it = tid; it < n * n; it += nthreads) {
+        const int j = it / n, q = it - j * n;
+        const long long a = ti_s[j] + 1, b = ti_s[q] + 1;               // 1-prefixed root-to-leaf paths
+        const int Da = node_depth(ti_s[j]), Db = node_depth(ti_s[q]), Dm = Da < Db ? Da : Db;
+        const unsigned long long z = (unsigned long long)((a >> (Da - Dm)) ^ (b >> (Db - Dm)));
+        lcd[it] = (unsigned char)(z == 0 ? Dm : Dm - (64 - __builtin_clzll(z)));
+    }
+    __syncthreads();
+    if (PU_EXIT == 1) return;
+    // 1) links, one thread per entry: one pass down over q < j (prev: first hit per depth wins = the largest q), one pass over q > j
+    //    (last), one over all q (sib); then the values of first occurrences, all (entry, depth) loads in flight together
+    for (int j = tid; j < n; j += nthreads) {
+        const int D = node_depth(ti_s[j]);
+        const unsigned char *row = lcd + j * n;
+        int cov = -1;                                                    // depths 0 .. cov already have their previous occurrence
+        for (int d = 0; d < MAXH; d++) { prev[j][d] = -1; sib[j][d] = -1; }
+        for (int q = j - 1; q >= 0 && cov < D; q--) {
+            const int l = row[q];
+            for (int d = cov + 1; d <= l; d++) prev[j][d] = (short)q;
+            cov = l > cov ? l : cov;
+        }
+        int covn = -1, rep = j;                                          // depths 0 .. covn have a LATER occurrence
+        for (int q = j + 1; q < n; q++) { const int l = row[q]; covn = l > covn ? l : covn; rep = l == D ? q : rep; }      // (lcd == D: the same leaf)
+        lastm[j] = covn + 1 > D ? 0u : (~0u << (covn + 1));              // bit d set: entry j is the last one touching its depth-d ancestor
+        rep_s[j] = rep;
+        unsigned sm = 0u;
+        for (int q = 0; q < n; q++) { const int l = row[q]; if (q != j && l < D) { sib[j][l] = (short)q; sm |= 1u << l; } }
+        if (sm) atomicOr(sibmask, sm);
+    }
+    __syncthreads();
+    if (PU_EXIT == 2) return;
     for (int it = tid; it < n * MAXH; it += nthreads) {
         const int j = it / MAXH, d = it - j * MAXH;
-        const long long ti = S.ti[j];
+        const long long ti = ti_s[j];
         const int D = node_depth(ti);
-        short pv = -1;
         double v = 0;
-        if (d <= D) {
-            const long long node = anc(ti, D, d);
-            if (MONOTONE) {
-                if (j > 0) { const int Dq = node_depth(S.ti[j - 1]); if (d <= Dq && anc(S.ti[j - 1], Dq, d) == node) pv = (short)(j - 1); }
-            } else {
-                for (int q = j - 1; q >= 0; q--) {
-                    const int Dq = node_depth(S.ti[q]);
-                    if (d <= Dq && anc(S.ti[q], Dq, d) == node) { pv = (short)q; break; }
-                }
-            }
-            if (pv < 0) v = P.tree[node];
+        if (d <= D && prev[j][d] < 0) v = P.tree[anc(ti, D, d)];
+        val[j][d] = v;
+    }
+    // (the heaps' pre-loads: thread j's off-path children, every level, requested now and used after the walk)
+    double smx[MAXH - 1], smn[MAXH - 1];
+    {
+        const int j = tid < n ? tid : 0;
+        const long long ti = ti_s[j];
+        const int D = node_depth(ti);
+#pragma unroll
+        for (int d = 0; d < MAXH - 1; d++) {
+            const bool need = tid < n && d < D && sib[j][d] < 0;
+            const long long on = d < D ? anc(ti, D, d + 1) : 1;          // j's node at depth d + 1; its sibling is the other child of the parent
+            const long long off = need ? (((on + 1) ^ 1) - 1) : 0;
+            smx[d] = P.maxt[off]; smn[d] = P.mint[off];
         }
-        S.val[j][d] = v; S.prev[j][d] = pv;
     }
     __syncthreads();
-    // 2) the ordered walk, first wave only
+    if (PU_EXIT == 3) { if (smx[3] == 1.2345 && smn[7] == 2.5) P.dev->error = 7; return; }
+    // 2) the ordered walk, first wave only.  Per entry the dependent chain is: ONE LDS read (the node's current value) -> subtract / add
+    //    -> one LDS write; everything else is off it -- the duplicate links and the leaf depths of 32 entries at a time are fetched into
+    //    registers up front, and the leaf lane's change reaches the others through v_readlane (the leaf depth is wave-uniform), not
+    //    through the LDS crossbar.  (With the links and depths read inside the loop a step took ~190 ns: 6 us for 32 entries.)
     if (tid < 64) {
         const int d = tid;
-        for (int j = 0; j < n; j++) {
-            const int D = node_depth(S.ti[j]);
-            double change = 0;
-            if (d == D) {
-                const short pv = S.prev[j][d];
-                const double old = pv >= 0 ? S.val[pv][d] : S.val[j][d];
-                change = S.p[j] - old;                           // :63
-                S.val[j][d] = S.p[j];                            // :64
+        for (int jb = 0; jb < n; jb += 32) {
+            int pvr[32], Dl = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) pvr[k] = jb + k < n && d < MAXH ? (int)prev[jb + k][d] : -1;
+            if (jb + (d & 31) < n) Dl = node_depth(ti_s[jb + (d & 31)]);           // lane k (and k + 32) holds entry jb + k's leaf depth
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int j = jb + k;
+                if (j < n) {                                             // (uniform)
+                    const int D = __builtin_amdgcn_readlane(Dl, k);
+                    const int pv = pvr[k];
+                    double old = 0;
+                    if (d <= D) old = pv >= 0 ? val[pv][d] : val[j][d];
+                    double change = p_s[j] - old;                        // meaningful on the leaf's lane (:63)
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(change), D), hi = __builtin_amdgcn_readlane(__double2hiint(change), D);
+                    change = __hiloint2double(hi, lo);
+                    if (d == D) val[j][d] = p_s[j];                      // :64
+                    else if (d < D) val[j][d] = old + change;            // :66-68
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
-            change = __shfl(change, D);
-            if (d < D) {
-                const short pv = S.prev[j][d];
-                const double old = pv >= 0 ? S.val[pv][d] : S.val[j][d];
-                S.val[j][d] = old + change;                      // :66-68
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
-    // 3) write back: one depth per thread, list order, so the last occurrence of a node wins
-    for (int d = tid; d < MAXH; d += nthreads)
-        for (int j = 0; j < n; j++) {
-            const int D = node_depth(S.ti[j]);
-            if (d <= D) P.tree[anc(S.ti[j], D, d)] = S.val[j][d];
-        }
-    // 4) max / min heaps: leaves (last occurrence wins), then ancestors bottom-up
-    for (int j = tid; j < n; j += nthreads) {
-        bool last = true;
-        for (int q = j + 1; q < n; q++) if (S.ti[q] == S.ti[j]) { last = false; break; }
-        if (last) { P.maxt[S.ti[j]] = S.p[j]; P.mint[S.ti[j]] = S.p[j]; }
+    if (PU_EXIT == 4) { if (smx[3] == 1.2345 && smn[7] == 2.5) P.dev->error = 7; return; }
+    // 3) write back: the last occurrence of every touched node
+    for (int it = tid; it < n * MAXH; it += nthreads) {
+        const int j = it / MAXH, d = it - j * MAXH;
+        const long long ti = ti_s[j];
+        const int D = node_depth(ti);
+        if (d <= D && ((lastm[j] >> d) & 1u)) P.tree[anc(ti, D, d)] = val[j][d];
     }
-    for (int d = MAXH - 2; d >= 0; d--) {
-        __threadfence_block();
-        __syncthreads();
-        for (int j = tid; j < n; j += nthreads) {
-            const int D = node_depth(S.ti[j]);
-            if (d < D) {
-                const long long node = anc(S.ti[j], D, d);
-                const double a = P.maxt[2 * node + 1], b = P.maxt[2 * node + 2];
-                const double c = P.mint[2 * node + 1], e = P.mint[2 * node + 2];
-                P.maxt[node] = a > b ? a : b;
-                P.mint[node] = c < e ? c : e;
+    // 4) max / min heaps: thread j climbs from its leaf (the LAST occurrence's p: later duplicates win) to the root
+    {
+        const int j = tid < n ? tid : 0;
+        const long long ti = ti_s[j];
+        const int D = node_depth(ti);
+        // the leaf's final value: p of the last entry with this leaf (later duplicates win)
+        double mx = p_s[rep_s[j]], mn = mx;
+        if (tid < n) { P.maxt[ti] = mx; P.mint[ti] = mn; }
+        const int Dtop = node_depth(2 * P.cap - 2);                      // the deeper leaf level: the loop below is uniform over the block
+        const unsigned readers = *sibmask;
+        // Entries exchange values only at levels where some sibling subtree is touched as well (`readers`: for a random batch in a big tree
+        // that is the top few levels): a level with readers is fed by an LDS write + ONE barrier at the end of the level below it; the
+        // other levels are thread-local.  (The barrier waits for LDS traffic only: __syncthreads() would also drain the global stores of
+        // every level -- nobody in this workgroup reads them -- one store round trip per level.)
+        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        int par = 0;
+        const int dfirst = Dtop - 1;
+        if (dfirst >= 0 && ((readers >> dfirst) & 1u)) {                 // (uniform)
+            if (tid < n) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
+            lds_barrier();
+        }
+#pragma unroll
+        for (int d = MAXH - 2; d >= 0; d--) {
+            if (d < Dtop) {                                              // (uniform)
+                if (tid < n && d < D) {
+                    const int sq = sib[j][d];
+                    const double omx = sq >= 0 ? cur[(par * 2 + 0) * n + sq] : smx[d], omn = sq >= 0 ? cur[(par * 2 + 1) * n + sq] : smn[d];
+                    mx = omx > mx ? omx : mx;
+                    mn = omn < mn ? omn : mn;
+                    const long long node = anc(ti, D, d);
+                    P.maxt[node] = mx; P.mint[node] = mn;
+                }
+                if (d > 0 && ((readers >> (d - 1)) & 1u)) {              // the next level has readers: publish this level's values
+                    par ^= 1;
+                    if (tid < n) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
+                    lds_barrier();
+                }
             }
         }
     }
-    __threadfence_block();
-    __syncthreads();
 }
 
 // Memory.store for `count` new transitions (BrainPrioritizedReplyDQN.py:121-125, add :50-60), reference order, parallel over
@@ -285,13 +379,14 @@ __device__ void per_apply_updates(const ReplayParams &P, UpdScratch &S, int n, i
 // 457 us -> ~10 us).  max / min heaps: every stored leaf holds p, the global maximum, so maxt = p on every touched node and
 // mint = p on every node whose leaves are all new; the (at most two per level) partially covered edge nodes take the minimum of
 // their children, walked bottom-up by one thread with the untouched siblings' values loaded up front.
-constexpr int PS_CHUNK = 4096;               // leaves per pass (their changes live in LDS)
-
-__global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int count) {
-    __shared__ double chg[PS_CHUNK];
-    __shared__ double sibv[4 * MAXH];       // min-heap values of the untouched children of the edge nodes, fetched up front
-    __shared__ long long lvl_lo[MAXH];
-    __shared__ int lvl_off[MAXH + 1];
+// TH threads, CHUNK leaves per pass (their changes live in LDS), GRP = the group size of the ordered-add pipeline.  Two shapes:
+//   <1024, 4096, 16>  the in-line launch (fb_replay_push on the caller's stream): as wide as a workgroup gets
+//   < 256, 2048,  8>  the RUN-AHEAD launch (fb_replay_per_store_ahead): one wave per SIMD, <= 64 registers, 17 KB of LDS -- the shape that
+//                     fits on a CU BESIDE a workgroup of the acting trunk (2 waves x 224 registers per SIMD, 133 KB of LDS), so the store
+//                     starts the moment its stream is released instead of waiting for that launch to drain.  The root's chain of ordered
+//                     fp64 additions -- the critical path -- is the same length either way; the parallel parts are a few per cent of it.
+template <int TH, int CHUNK, int GRP>
+__device__ __forceinline__ void per_store_body(const ReplayParams &P, int count, double *chg, double *sibv, long long *lvl_lo, int *lvl_off) {
     const int tid = threadIdx.x;
     long long pointer = P.dev->per_pointer, size = P.dev->per_size;
     // first data slot whose leaf sits on the deeper level (heap index >= 2^D - 1)
@@ -300,7 +395,7 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
     int done = 0;
     while (done < count) {
         long long n = count - done;
-        if (n > PS_CHUNK) n = PS_CHUNK;
+        if (n > CHUNK) n = CHUNK;
         if (n > P.cap - pointer) n = P.cap - pointer;             // do not cross the ring wrap
         if (pointer < deep0 && pointer + n > deep0) n = deep0 - pointer;   // nor the leaf depth change: one depth per pass
         // np.max over all leaves: storing max_p never changes the maximum, re-read per pass anyway
@@ -310,14 +405,14 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
         const long long leaf_lo = pointer + P.cap - 1, leaf_hi = leaf_lo + n - 1;
         const int D = node_depth(leaf_lo);
         // 1) the leaves: change_j = p - old (:63), leaf = p (:64)
-        for (int j = tid; j < (int)n; j += 1024) {
+        for (int j = tid; j < (int)n; j += TH) {
             const long long leaf = leaf_lo + j;
             chg[j] = max_p - P.tree[leaf];
             P.tree[leaf] = max_p; P.maxt[leaf] = max_p; P.mint[leaf] = max_p;
         }
         if (tid < D) lvl_lo[tid] = anc(leaf_lo, D, tid);
-        if (tid >= 512 && tid < 512 + 4 * D) {                   // (level d, edge e, child k): one load each, all in flight together --
-            const int q = tid - 512, d = q >> 2, e = (q >> 1) & 1, k = (q & 1) + 1;      // the walk in 3) then never waits for memory
+        if (tid >= TH / 2 && tid < TH / 2 + 4 * D) {             // (level d, edge e, child k): one load each, all in flight together --
+            const int q = tid - TH / 2, d = q >> 2, e = (q >> 1) & 1, k = (q & 1) + 1;      // the walk in 3) then never waits for memory
             const long long a = e ? anc(leaf_hi, D, d) : anc(leaf_lo, D, d), c = 2 * a + k;
             const int sh1 = D - d - 1;
             const long long Lc = ((c + 1) << sh1) - 1, Rc = ((c + 2) << sh1) - 2;
@@ -331,7 +426,7 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
         __syncthreads();
         // 2) every touched internal node adds the changes of the leaves under it, in list order (:66-68)
         const int total = lvl_off[D];
-        for (int task = tid; task < total; task += 1024) {
+        for (int task = tid; task < total; task += TH) {
             int d = 0;
             while (d + 1 < D && lvl_off[d + 1] <= task) d++;
             const long long a = lvl_lo[d] + (task - lvl_off[d]);
@@ -340,27 +435,27 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
             const int jlo = (int)((L > leaf_lo ? L : leaf_lo) - leaf_lo), jhi = (int)((R < leaf_hi ? R : leaf_hi) - leaf_lo);
             double v = P.tree[a];
             int j = jlo;
-            // groups of 16: the LDS reads of the NEXT group are in flight while this group's 16 dependent fp64 adds run (the adds stay
+            // groups of GRP: the LDS reads of the NEXT group are in flight while this group's dependent fp64 adds run (the adds stay
             // in list order; the root's chain is the launch's critical path: one LDS latency per 8 adds made it ~15 ns per leaf)
-            if (j + 16 <= jhi + 1) {
+            if (j + GRP <= jhi + 1) {
                 // (two register sets used alternately -- no copies: v_mov_b64 costs as much as the v_add_f64 it would sit beside)
-                double c[16], nx[16];
+                double c[GRP], nx[GRP];
 #pragma unroll
-                for (int q = 0; q < 16; q++) c[q] = chg[j + q];
-                while (j + 16 <= jhi + 1) {
-                    const bool m1 = j + 32 <= jhi + 1;
+                for (int q = 0; q < GRP; q++) c[q] = chg[j + q];
+                while (j + GRP <= jhi + 1) {
+                    const bool m1 = j + 2 * GRP <= jhi + 1;
 #pragma unroll
-                    for (int q = 0; q < 16; q++) nx[q] = chg[m1 ? j + 16 + q : j + q];
+                    for (int q = 0; q < GRP; q++) nx[q] = chg[m1 ? j + GRP + q : j + q];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) v += c[q];
-                    j += 16;
+                    for (int q = 0; q < GRP; q++) v += c[q];
+                    j += GRP;
                     if (!m1) break;
-                    const bool m2 = j + 32 <= jhi + 1;
+                    const bool m2 = j + 2 * GRP <= jhi + 1;
 #pragma unroll
-                    for (int q = 0; q < 16; q++) c[q] = chg[m2 ? j + 16 + q : j + q];
+                    for (int q = 0; q < GRP; q++) c[q] = chg[m2 ? j + GRP + q : j + q];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) v += nx[q];
-                    j += 16;
+                    for (int q = 0; q < GRP; q++) v += nx[q];
+                    j += GRP;
                     if (!m2) break;
                 }
             }
@@ -370,7 +465,7 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
             if (L >= leaf_lo && R <= leaf_hi) P.mint[a] = max_p;     // all its leaves are new
         }
         // 3) the minimum heap on the partially covered edge nodes (<= 2 per level), bottom-up, by one thread beside 2)
-        if (tid == 1023) {
+        if (tid == TH - 1) {
             double m_lo = max_p, m_hi = max_p;                   // values of the level below's edge nodes (the leaves: p)
             for (int d = D - 1; d >= 0; d--) {
                 const long long lo = anc(leaf_lo, D, d), hi = anc(leaf_hi, D, d), clo = anc(leaf_lo, D, d + 1), chi = anc(leaf_hi, D, d + 1);
@@ -404,6 +499,22 @@ __global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int cou
     }
     __syncthreads();
     if (tid == 0) { P.dev->per_pointer = pointer; P.dev->per_size = size; }
+}
+
+__global__ __launch_bounds__(1024) void per_store_kernel(ReplayParams P, int count) {
+    __shared__ double chg[4096];
+    __shared__ double sibv[4 * MAXH];       // min-heap values of the untouched children of the edge nodes, fetched up front
+    __shared__ long long lvl_lo[MAXH];
+    __shared__ int lvl_off[MAXH + 1];
+    per_store_body<1024, 4096, 16>(P, count, chg, sibv, lvl_lo, lvl_off);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void per_store_slim_kernel(ReplayParams P, int count) {
+    __shared__ double chg[2048];
+    __shared__ double sibv[4 * MAXH];
+    __shared__ long long lvl_lo[MAXH];
+    __shared__ int lvl_off[MAXH + 1];
+    per_store_body<256, 2048, 8>(P, count, chg, sibv, lvl_lo, lvl_off);
 }
 
 // ---- FB_PER_FAST: the same heaps kept by RECOMPUTATION instead of the reference's running sums.  A node is
@@ -496,13 +607,15 @@ __global__ __launch_bounds__(256) void per_update_fast_kernel(ReplayParams P, in
 __global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, const long long *__restrict__ idx,
                                                          float *__restrict__ abs_err,
                                                          const float *__restrict__ prio) {
-    extern __shared__ unsigned char smem[];
-    UpdScratch &S = *reinterpret_cast<UpdScratch *>(smem);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const UpdLayout Lo(n);
+    long long *ti_w = reinterpret_cast<long long *>(smem + Lo.ti);
+    double *p_w = reinterpret_cast<double *>(smem + Lo.p);
     const int tid = threadIdx.x;
     for (int j = tid; j < n; j += 256) {
         long long ti = idx[j];
         if (ti < P.cap - 1 || ti > 2 * P.cap - 2) { P.dev->error = 1; ti = P.cap - 1; }
-        S.ti[j] = ti;
+        ti_w[j] = ti;
         float ps;
         if (prio) ps = prio[j];
         else {
@@ -511,10 +624,10 @@ __global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, 
             const float c = e < 1.0f ? e : 1.0f;                 // np.minimum(.., abs_err_upper)
             ps = (float)pow((double)c, (double)0.6f);            // np.power(fp32, 0.6) -> fp32
         }
-        S.p[j] = (double)ps;
+        p_w[j] = (double)ps;
     }
     __syncthreads();
-    per_apply_updates<false>(P, S, n, tid, 256);
+    per_apply_updates(P, smem, n, tid, 256);
 }
 
 // Memory.sample (BrainPrioritizedReplyDQN.py:127-144)
@@ -733,7 +846,7 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
     hipStream_t st = fb_stream(stream);
     if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;
     if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
-    else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
+    else hipLaunchKernelGGL(per_store_slim_kernel, dim3(1), dim3(256), 0, h->side, h->P, h->P.n_envs);     // (the shape that fits beside the acting trunk)
     if (hipEventRecord(h->ev_store, h->side) != hipSuccess) { (void)hipStreamWaitEvent(st, h->ev_fork, 0); return 0; }
     h->store_ahead = true;
     return 1;
@@ -864,9 +977,16 @@ extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64
     if (h->per_mode == FB_PER_FAST)
         hipLaunchKernelGGL(per_update_fast_kernel, dim3(1), dim3(256), 0, fb_stream(stream), h->P, batch, (const long long *)idx, abs_err,
                            priorities_or_null);
-    else
-        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), sizeof(UpdScratch), fb_stream(stream), h->P, batch,
+    else {
+        const size_t bytes = (size_t)UpdLayout(batch).bytes;                 // 10 KB at a batch of 32, 150 KB at 256
+        static size_t allowed = 48 * 1024;                                   // (dynamic LDS beyond the default limit has to be asked for, once)
+        if (bytes > allowed) {
+            FB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(per_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            allowed = bytes;
+        }
+        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), bytes, fb_stream(stream), h->P, batch,
                            (const long long *)idx, abs_err, priorities_or_null);
+    }
     FB_LAUNCH_CHECK();
     return FB_OK;
 }

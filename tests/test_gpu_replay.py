@@ -390,3 +390,44 @@ def test_full_size_ring_addressing_one_million_slots(torch_cuda):
             assert np.array_equal(s2[b, :, :, f].cpu().numpy(), unpack(max(stp[b] - 3 + f, 0), env[b])), (b, f)
         am, rm, tm = meta(int(stp[b]))
         assert (int(a[b]), float(r[b]), int(t[b])) == (int(am[env[b]]), float(rm[env[b]]), int(tm[env[b]]))
+
+
+@pytest.mark.parametrize("cap,B,pool", [(50, 200, 30), (1000, 256, 90), (50000, 200, 5000), (50000, 32, 12)])
+def test_per_batch_update_long_lists_with_duplicates(torch_cuda, cap, B, pool):
+    """Memory.batch_update (BrainPrioritizedReplyDQN.py:146-151) on lists longer than a wave and full of duplicates (the leaves are drawn
+    from a pool smaller than the list), leaves on both levels of the heap: the tree bytes stay the reference's (later duplicates win, every
+    ancestor's running sum in list order), and so do the max / min heaps -- checked through what reads them: Memory.sample's importance
+    weights divide by the minimum leaf, Memory.store writes the maximum leaf."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import VecReplay
+    from oracle import oracle as o
+    rep = VecReplay(cap, 1, prioritized=True)
+    z8 = torch.zeros((1, 100), dtype=torch.int64, device="cuda")
+    za, zr = torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.float32, device="cuda")
+    rep.reset(z8)
+    mem = o.Memory(cap)
+    fill = min(cap, 3000)
+    for _ in range(fill):
+        rep.push(z8, za, zr, za)
+    mem.store(fill)
+    rng = np.random.default_rng(cap + B)
+    for rnd in range(6):
+        leaves = rng.choice(fill, size=min(pool, fill), replace=False)
+        idx = (rng.choice(leaves, size=B) + cap - 1).astype(np.int64)
+        if rnd == 3:
+            idx[:] = idx[0]                                         # one leaf, B times
+        ps = (rng.random(B).astype(np.float32) * 1.3 + 0.005).clip(max=1.0) ** np.float32(0.6)
+        rep.update_priorities(torch.from_numpy(idx).cuda(), priorities=torch.from_numpy(ps).cuda())
+        mem.batch_update_p(idx.astype(np.int32), ps)
+        tree, ptr, size, beta = rep.per_state()
+        assert np.array_equal(tree.view(np.uint64), mem.tree.view(np.uint64)), rnd
+        u = rng.random(32)
+        di, dw = rep.sample(32, uniforms=torch.from_numpy(u).cuda())
+        oi, ow = mem.sample(32, u=u)
+        assert di.cpu().tolist() == list(oi)
+        np.testing.assert_allclose(dw.cpu().numpy(), ow, rtol=1e-13)      # (p / total / min_prob)^-beta: the MINIMUM heap
+        rep.push(z8, za, zr, za)                                     # stores the MAXIMUM leaf
+        mem.store(1)
+        tree, ptr, size, beta = rep.per_state()
+        assert (ptr, size) == (mem.data_pointer, mem.size)
+        assert np.array_equal(tree.view(np.uint64), mem.tree.view(np.uint64)), rnd

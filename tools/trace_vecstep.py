@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
-n, B = 1024, 32
+n, B = int(os.environ.get("FB_TRACE_ENVS", "1024")), int(os.environ.get("FB_TRACE_BATCH", "32"))
 env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n), QNet(max_batch=n)
 replay.seed(0, "cpython")
 net.init_params(0)
