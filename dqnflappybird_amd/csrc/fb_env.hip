@@ -583,7 +583,9 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
     h->p.n_envs = n_envs;
     h->p.seed_lo = (uint32_t)seed; h->p.seed_hi = (uint32_t)(seed >> 32);
     h->p.cst = h->d_const;
-    h->grid = n_envs < 2048 ? n_envs : 2048;
+    int cap = 2048;                                  // workgroups of the step launch: one per env up to here, then they stride
+    if (const char *g = getenv("FB_ENV_GRID_CAP")) { int v = atoi(g); if (v >= 256 && v <= 65536) cap = v; }      // tuning knob
+    h->grid = n_envs < cap ? n_envs : cap;
     if (const char *g = getenv("FB_ENV_GRID")) { int v = atoi(g); if (v > 0 && v < h->grid) h->grid = v; }   // tuning knob
     *out = h;
     return fb_env_reset(h, nullptr);
