@@ -220,6 +220,19 @@ def main():
     dt_tr_eager = median(dts_tr_eager)
     grad_steps_eager = world * args.steps / dt_tr_eager
 
+    # ---------------------------------------------------------------- N > 1: the data-parallel invariant, checked on the run itself
+    # every rank started from the same parameters and applied the same reduced gradients in legs A and C, so the replicas must still be
+    # bit-identical (element-wise MIN == MAX over ranks; a NaN fails it too).  Outside every timed region.
+    replicas_identical = None
+    if world > 1:
+        lo = net.store_params()
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+        if not replicas_identical and rank == 0:
+            print(f"[bench] REPLICAS DIVERGED: {int((lo != hi).sum())} of {lo.numel()} parameters differ between ranks", file=sys.stderr)
+
     # ---------------------------------------------------------------- leg D: per-kernel HIP-event timing
     kernels = []
     roofline = None
@@ -455,6 +468,7 @@ def main():
                        "train_only": {"grad_steps_per_sec": round(grad_steps_per_s, 1), "us_per_grad_step": round(1e6 * world / grad_steps_per_s, 2),
                                       "grad_steps_per_sec_eager": round(grad_steps_eager, 1)},
                        "env_only_steps_per_sec": round(env_only, 1),
+                       "replicas_bit_identical": replicas_identical,       # (N > 1 only: parameters compared across ranks after the timed legs)
                        "parallelism": (f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat gradient per step"
                                        + (" (fb_vec_step_dp: issued from the C side in two pieces, the W_fc1 / head part overlapped with the conv backward)"
                                           if native is not None else " (torch.distributed)")) if world > 1 else "single GPU"},

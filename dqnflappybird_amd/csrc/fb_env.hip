@@ -25,8 +25,18 @@ namespace {
 #include "fb_head.h"              // ... and so can the acting path's head (fc2 + epsilon-greedy action of this env)
 
 constexpr int SW = 288, SH = 512, PIPE_W = 52, PIPE_H = 320, BIRD_W = 34, BIRD_H = 24;
+#ifndef ENV_HITMASK
+#define ENV_HITMASK 1   // 0: the per-pixel collision test against the sprite in global memory (A/B builds)
+#endif
+#ifndef ENV_EXIT
+#define ENV_EXIT 0      // measurement builds only (tools/abl_env.sh): leave the step kernel after phase 1..4
+#endif
 constexpr int BASE_W = 336, BASE_H = 112, BASEY_I = 404, PLAYERX = 57, GAP = 100, OBS = 80;
-constexpr int ENV_THREADS = 512;  // 8 waves: the 80 output rows of an env are rendered 8 at a time
+#ifndef ENV_THREADS_N
+#define ENV_THREADS_N 256
+#endif
+constexpr int ENV_THREADS = ENV_THREADS_N;  // 4 waves (measured: 512 threads 17.2 us in the loop at 1024 envs, 256: 11.8, 128: 13.7, 64: 18.5)
+constexpr int NIB_PRE = (800 + ENV_THREADS - 1) / ENV_THREADS;   // a thread's words of the old nibble image
 constexpr int GROUND_C0 = 63;    // first observation column whose taps all lie in the ground sprite
 constexpr int PIPE_DX = PIPE_W + 1, BIRD_ROWS = 12;
 constexpr size_t BLOB_BYTES = 8 + 4 + 1024 + PIPE_H * PIPE_W + 3 * BIRD_H * BIRD_W + BASE_H * BASE_W;
@@ -45,6 +55,9 @@ struct alignas(16) EnvLds {      // staged into LDS by every workgroup
     uint8_t bird_pat[3 * BIRD_ROWS * 32];
     uint8_t bird_cb[32];                 // first column of that pattern for y % 32
     int16_t bird_r0, bird_nr, pad_[6];   // observation rows whose x taps touch the bird
+    // hit masks (wrapped_flappy_bird.py:285-300, getHitmask): bit c of row r = the sprite's pixel (r, c) is opaque
+    unsigned long long pipe_hit[PIPE_H];
+    unsigned long long bird_hit[3 * BIRD_H];
 };
 static_assert(sizeof(EnvLds) % 16 == 0, "EnvLds must be a multiple of 16 bytes");
 
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
     }
     int32_t st0[16];
     int act0 = 0;
-    uint32_t nib0[2] = {0u, 0u};
+    uint32_t nib0[NIB_PRE] = {};
     {
         const int env = bid;                        // < n_envs: the grid never exceeds the env count
 #pragma unroll
@@ -166,9 +179,11 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
         if (STEP && !head.on) act0 = actions[env];
         if (STEP && p.nib) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nib + (size_t)env * FB_NIB_STRIDE);
-            const int w1 = threadIdx.x + ENV_THREADS < 800 ? threadIdx.x + ENV_THREADS : 0;
-            nib0[0] = src[nib_word(threadIdx.x)];
-            nib0[1] = src[nib_word(w1)];
+#pragma unroll
+            for (int k = 0; k < NIB_PRE; k++) {
+                const int w = threadIdx.x + k * ENV_THREADS;
+                nib0[k] = src[nib_word(w < 800 ? w : 0)];
+            }
         }
         const uint4 *src = reinterpret_cast<const uint4 *>(&p.cst->l);
         uint4 *dst = reinterpret_cast<uint4 *>(&L);
@@ -181,6 +196,15 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
         }
     }
     __syncthreads();
+#if ENV_EXIT == 1
+    if (STEP) return;
+#elif ENV_EXIT == 5     // ... with the head rider's action and the state loads kept alive
+    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail : act0); return; }
+#elif ENV_EXIT == 6     // ... and the staged tables
+    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail : act0) + (int)L.bird_hit[st0[2] * BIRD_H] + (int)L.pal[st0[3]]; return; }
+#elif ENV_EXIT == 7     // the staged tables without the head rider
+    if (STEP) { if (threadIdx.x == 0) score[bid] = (int)L.bird_hit[(bid & 1) * BIRD_H] + (int)L.pal[bid & 255]; return; }
+#endif
     if (STEP && head.on) act0 = act_mail;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -229,6 +253,26 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
                     if (i < st[6] && st[7 + i] <= 48 && st[7 + i] > 44) { st[5] += 1; rew = 3.0f; }
                 // pixel-exact pipe collision, :255-273 -- every bird pixel against the pipe on top of it
                 int hit = 0;
+#if ENV_HITMASK
+                // one thread per bird row: the row's 34 hit bits against the hit bits of every pipe under them (checkCrash, :255-273: a hit
+                // on ANY pipe's mask counts), all from LDS -- no dependent global loads
+                if (!ground && threadIdx.x < BIRD_H) {
+                    const int by = threadIdx.x, y = st[0] + by;
+                    const unsigned long long bm = L.bird_hit[st[2] * BIRD_H + by];
+                    unsigned long long under = 0ull;              // bit bx: an opaque pipe pixel under bird column bx
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int d = PLAYERX - st[7 + i], gy = gap_y(st[10 + i]);        // pipe column of bird column bx: bx + d
+                        if (i < st[6] && d > -64 && d < PIPE_W && (y < gy || y >= gy + GAP)) {
+                            const int row = y < gy ? gy - 1 - y : y - gy - GAP;
+                            const unsigned long long raw = L.pipe_hit[row < PIPE_H ? row : PIPE_H - 1];
+                            const unsigned long long pm = y < gy ? __brevll(raw) >> (64 - PIPE_W) : raw;     // upper pipe: rotated by 180
+                            under |= d >= 0 ? pm >> d : pm << -d;
+                        }
+                    }
+                    hit = y < BASEY_I && (under & bm) != 0ull;
+                }
+#else
                 if (!ground) {
                     for (int i = threadIdx.x; i < BIRD_W * BIRD_H; i += ENV_THREADS) {
                         const int bx = i % BIRD_W, by = i / BIRD_W;
@@ -238,7 +282,11 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
                         }
                     }
                 }
+#endif
                 const int crash = __syncthreads_or(hit | ground);
+#if ENV_EXIT == 2
+                if (STEP) return;
+#endif
                 score_ret = st[5];                                // :155
                 if (crash) { term = 1; env_reset(p, env, st); rew = -3.0f; }          // :157-162
             }
@@ -282,8 +330,8 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
         // lookup (EnvLds::pipe_mask / bird_pat: the same four-tap arithmetic, done once on the host for every sprite
         // offset and tap phase); a row whose taps touch the bird AND a pipe goes to the per-pixel path below, which
         // resolves every tap against the sprite on top (at most the 9 bird rows, only while a pipe passes the bird).
-        if (threadIdx.x < OBS) {
-            const int r = threadIdx.x, x0 = L.xo[r], ph = r % 5;
+        for (int r = threadIdx.x; r < OBS; r += ENV_THREADS) {
+            const int x0 = L.xo[r], ph = r % 5;
             unsigned long long m = 0ull;
             bool haspipe = false;
 #pragma unroll
@@ -341,9 +389,11 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
             if (lane == 0) rowm[r] = m;
         }
         __syncthreads();
+#if ENV_EXIT == 3
+        if (STEP) return;
+#endif
         // a row's 80 bits (63 rendered + 17 ground) are OR-ed into the frame's 100 packed words (a row straddles two or three)
-        if (threadIdx.x < OBS) {
-            const int r = threadIdx.x;
+        for (int r = threadIdx.x; r < OBS; r += ENV_THREADS) {
             const unsigned long long g = L.ground_bits[gidx * OBS + r];           // 17 bits, columns 63..79
             const int p0 = r * OBS, w0 = p0 >> 6, sh = p0 & 63;                   // row = bits [p0, p0 + 80)
             const unsigned long long lo = rowm[r] | (g << GROUND_C0);             // columns 0..63 (bit 63 = column 63)
@@ -354,6 +404,9 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
             if (sh > 48) atomicOr(&fw[w0 + 2], hi >> (64 - sh));
         }
         __syncthreads();
+#if ENV_EXIT == 4
+        if (STEP) return;
+#endif
         if (frame_bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) frame_bits[(size_t)env * 100 + w] = fw[w];
         if (STEP && push.bits) for (int w = threadIdx.x; w < 100; w += ENV_THREADS) push.bits[(size_t)env * 100 + w] = fw[w];   // ... and its frame
         if (p.nib) {
@@ -367,14 +420,17 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
                     if (row < 2 || row >= 82 || col == 0) dst[w] = 0u;
                 }
             }
-            for (int w = threadIdx.x; w < 800; w += ENV_THREADS) {
+#pragma unroll
+            for (int k = 0; k < NIB_PRE; k++) {
+                const int w = threadIdx.x + k * ENV_THREADS;
+                if (w >= 800) break;
                 const unsigned t = (unsigned)(fw[w >> 3] >> ((w & 7) * 8)) & 0xFFu;       // the 8 new pixel bits
                 uint32_t top = 0;
 #pragma unroll
                 for (int m = 0; m < 8; m++) top |= ((t >> m) & 1u) << (4 * m + 3);
                 uint32_t old = 0u;
                 const int pw = nib_word(w);
-                if (STEP) old = first ? (w >= ENV_THREADS ? nib0[1] : nib0[0]) : dst[pw];     // (no run-time register index: scratch)
+                if (STEP) old = first ? nib0[k] : dst[pw];                                // (k is a compile-time index: the loop is unrolled)
                 dst[pw] = STEP ? (((old >> 1) & 0x77777777u) | top) : (top | (top >> 1) | (top >> 2) | (top >> 3));
             }
         }
@@ -537,6 +593,16 @@ extern "C" int fb_env_create(int n_envs, uint64_t seed, uint32_t flags, const vo
                 }
                 hc->l.pipe_mask[(g * PIPE_DX + dx) * 5 + ph] = m;
             }
+    for (int r = 0; r < PIPE_H; r++) {
+        unsigned long long m = 0;
+        for (int c = 0; c < PIPE_W; c++) m |= (unsigned long long)(hc->pipe[r * PIPE_W + c] != 0) << c;
+        hc->l.pipe_hit[r] = m;
+    }
+    for (int r = 0; r < 3 * BIRD_H; r++) {
+        unsigned long long m = 0;
+        for (int c = 0; c < BIRD_W; c++) m |= (unsigned long long)(hc->l.bird[r * BIRD_W + c] != 0) << c;
+        hc->l.bird_hit[r] = m;
+    }
     int br0 = -1, bnr = 0;
     for (int r = 0; r < OBS; r++)
         if (hc->l.xo[r] + 1 >= PLAYERX && hc->l.xo[r] < PLAYERX + BIRD_W) { if (br0 < 0) br0 = r; bnr = r - br0 + 1; }
