@@ -174,7 +174,8 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // ring.  Memories that cannot ride keep their own launches (same results).
     FbSampleRider srider;
     FbPushRider prider;
-    const int have_s = train ? fb_replay_sample_rider(replay, batch, b->idx, &srider) : 0;      // before the push is counted
+    static const bool sample_rides = !(getenv("FB_VEC_SAMPLE_RIDER") && atoi(getenv("FB_VEC_SAMPLE_RIDER")) == 0);      // A/B knob
+    const int have_s = train && sample_rides ? fb_replay_sample_rider(replay, batch, b->idx, &srider) : 0;      // before the push is counted
     const int have_p = fb_replay_begin_push_rider(replay, &prider);
     rc = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, have_s ? &srider : nullptr,
                            have_p ? &prider : nullptr, have_h ? &hrider : nullptr, stream);
