@@ -6,9 +6,9 @@
 //   checkCrash / pixelCollision       game/wrapped_flappy_bird.py:244-300
 //   preprocess                        FlappyBirdDQN.py:31-34
 //
-// Design (DESIGN.md "Kernel E"):  one 512-thread workgroup walks envs e = blockIdx.x, +gridDim.x.
-// The pipe / bird sprites (palette indices), the palette, the resize tap tables and a
-// pre-rendered table of the ground region live in LDS (25 KB, staged once per workgroup).
+// Design (DESIGN.md "Kernel E"):  one 256-thread workgroup walks envs e = blockIdx.x, +gridDim.x.
+// The bird sprite (palette indices), the palette, the resize tap tables, the pre-rendered pipe / bird / ground
+// row tables and the sprites' hit masks live in LDS (31 KB, staged once per workgroup).
 // The 288x512x3 canvas of the reference is never built: every output pixel of the 80x80
 // observation reads the four canvas pixels cv2.resize would read, resolved directly against the
 // sprite that is on top there, then applies OpenCV's fixed-point bilinear / gray / threshold.
