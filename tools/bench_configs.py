@@ -25,6 +25,7 @@ ROWS = [
     ("configs[3] PER, 1M-slot SumTree, 4096 envs, B=32, FB_PER_FAST", dict(n_envs=4096, algo="per", batch=32), "fast"),
     ("configs[4] per-GPU share: dueling, 4096 envs, B=32", dict(n_envs=4096, algo="nature", arch="dueling", batch=32), None),
     ("configs[4] per-GPU share: dueling Double-DQN, 4096 envs, B=32", dict(n_envs=4096, algo="double", arch="dueling", batch=32), None),
+    ("configs[4] whole-node env count on ONE GPU: dueling Double-DQN, 32768 envs, B=32", dict(n_envs=32768, algo="double", arch="dueling", batch=32), None),
 ]
 
 
