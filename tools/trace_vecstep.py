@@ -12,6 +12,7 @@ net.init_params(0)
 nib = env.track_state()
 env.observe(); replay.reset(env.frame_bits)
 one = VecStep(env, replay, net, B, "dqn")
+train = os.environ.get("FB_TRACE_TRAIN", "1") == "1"          # 0: act -> env -> push only (W_fc1's planes never go stale)
 for step in range(150):
-    one(0.03, seed=0, step=step)
+    one(0.03, seed=0, step=step, train=train)
 torch.cuda.synchronize()
