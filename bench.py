@@ -411,7 +411,7 @@ def main():
             g_["logical_frac"] = kk["frac"]
             g_["logical_basis"] = "SURVEY 8d: 102 417 B per sampled transition"
             if b == "B=32":
-                g_["bound"] = "latency (1 us of traffic in a dependent launch): the fractions are reported, not claimed"
+                g_["bound"] = "latency (1 us of traffic in a dependent launch; an EMPTY launch costs 2.8-3.3 us here, tools/mb/mb_launch.hip): the fractions are reported, not claimed"
             roofline["replay_gather"][b] = g_
         roofline["grad_steps_per_sec"] = round(grad_steps_per_s, 1)      # (the train-only half of BASELINE.json's metric, where the driver's record keeps it)
 
