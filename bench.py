@@ -366,6 +366,17 @@ def main():
         add("gather_kernel<true>[currentState n=1024]", us, 0, "hbm", 2 * 25_600 * N_ENVS)
         us = ev_time(lambda: [env.frame_step(acts, want_u8=False) for _ in range(R)], R)
         add("env_kernel<true>[n=1024]", us, 1, "lds", ENV_BYTES * N_ENVS)      # row-mask table lookups in LDS; 6.4 KB per env-step is no HBM load
+        # SURVEY 8(d) asks for the env step's LDS-bandwidth fraction.  LDS bytes per env-step, counted statically from csrc/fb_env.hip (no
+        # counter reports LDS bytes): a workgroup stages 29.6 KB of tables once, then per env moves ~17 KB (rows' table reads 3.6, frame
+        # assembly 4.6, nibble / ring / frame reads of the assembled words 8.0, collision 0.8).  One env per workgroup up to 2048 envs.
+        lds_peak = 256 * 128 * 2.4e9 / 1e12                  # TB/s: 256 CUs x 128 B / clk x 2.4 GHz
+        def lds_frac(n, rate):                               # rate = env-steps/s alone at n envs
+            per_wg = max(1, -(-n // 2048))
+            b = 17_000 + 29_600 / per_wg
+            return {"n_envs": n, "lds_bytes_per_env_step": round(b), "achieved_TBps": round(b * rate / 1e12, 2), "peak_TBps": round(lds_peak, 1),
+                    "frac": round(b * rate / 1e12 / lds_peak, 4)}
+        kernels[-1]["lds"] = [lds_frac(int(n), r) for n, r in env_by_n.items()]
+        kernels[-1]["lds_note"] = "static byte count, not a counter; at 6-11 % of the LDS peak the step is latency-bound (dependent chain per env), not LDS-bandwidth-bound"
         # prioritized replay (config 4: 1 M-slot SumTree in HBM): latency-bound tree walks -> us per batch, no BW fraction
         per = VecReplay(CAPACITY, N_ENVS, prioritized=True)
         per.seed(seed, "numpy")
