@@ -3,6 +3,7 @@
 #   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over the bench kernels      -> <tag>_pmc_fetch_write_raw.json, traffic json
 #   3. the per-config table (tools/bench_configs.py)                                  -> <tag>_configs.jsonl
 #   4. the plain bench line                                                           -> <tag>_bench.json
+#   5. SQ counter passes of the acting and the train kernels (MFMA busy, LDS, waits)  -> <tag>_pmc_sq.txt (MFMA utilisation table on top)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r03}
@@ -17,3 +18,10 @@ cp gpurun_out/${T}_traffic.json profiles/traffic.json      # (so that the bench 
 python3 tools/bench_configs.py --steps 100 --cpu --out gpurun_out/${T}_configs.jsonl > gpurun_out/${T}_configs.log 2>&1
 python3 bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 tail -c 400 gpurun_out/${T}_bench.json; cat gpurun_out/${T}_configs.jsonl
+bash tools/pmc_act.sh ${T}act > gpurun_out/${T}_pmc_sq_act.log 2>&1 && bash tools/pmc_train.sh ${T}train > gpurun_out/${T}_pmc_sq_train.log 2>&1 && {
+  echo "# rocprofv3 --pmc (SQ counters): tools/pmc_act.sh (acting forward, 1024 envs) and tools/pmc_train.sh (train step, B = 32, gathered-minibatch form)"
+  echo "## MFMA utilisation (tools/mfma_util.py)"
+  python3 tools/mfma_util.py $(find gpurun_out/pmc2_${T}act gpurun_out/pmc2_${T}train -name "*counter_collection.csv")
+  echo; echo "## per-kernel counter means (tools/pmc_summary.py)"
+  grep -hv "^W2026\|^E2026\|amdgpu.ids" gpurun_out/${T}_pmc_sq_act.log gpurun_out/${T}_pmc_sq_train.log
+} > gpurun_out/${T}_pmc_sq.txt
