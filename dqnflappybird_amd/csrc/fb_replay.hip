@@ -220,6 +220,52 @@ struct UpdLayout {                   // byte offsets inside the dynamic LDS bloc
     }
 };
 
+// 4) of per_apply_updates: the max / min heaps.  Heap thread hj (active: it owns entry j = hj) climbs from its leaf (the LAST occurrence's
+// p: later duplicates win) to the root.  Entries exchange values only at levels where some sibling subtree is touched as well (`readers`:
+// for a random batch in a big tree that is the top few levels): a level with readers is fed by an LDS write + ONE synchronisation at the
+// end of the level below it; the other levels are thread-local.  WAVE: all heap threads sit in one wave (n <= 64) -- waiting for the
+// wave's own LDS traffic is the whole synchronisation, and the climb can run BESIDE the ordered walk of another wave; otherwise a
+// workgroup barrier that waits for LDS traffic only (__syncthreads() would also drain the global stores of every level -- nobody in
+// this workgroup reads them -- one store round trip per level).
+template <bool WAVE>
+__device__ __forceinline__ void per_heaps(const ReplayParams &P, int n, bool active, int j, const long long *ti_s, const double *p_s,
+                                          const int *rep_s, short (*sib)[MAXH], unsigned readers, double *cur,
+                                          const double (&smx)[MAXH - 1], const double (&smn)[MAXH - 1]) {
+    auto level_sync = []() {
+        if (WAVE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    const long long ti = ti_s[j];
+    const int D = node_depth(ti);
+    double mx = p_s[rep_s[j]], mn = mx;                              // the leaf's final value: p of the last entry with this leaf
+    if (active) { P.maxt[ti] = mx; P.mint[ti] = mn; }
+    const int Dtop = node_depth(2 * P.cap - 2);                      // the deeper leaf level: the loop below is uniform over the block
+    int par = 0;
+    const int dfirst = Dtop - 1;
+    if (dfirst >= 0 && ((readers >> dfirst) & 1u)) {                 // (uniform)
+        if (active) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
+        level_sync();
+    }
+#pragma unroll
+    for (int d = MAXH - 2; d >= 0; d--) {
+        if (d < Dtop) {                                              // (uniform)
+            if (active && d < D) {
+                const int sq = sib[j][d];
+                const double omx = sq >= 0 ? cur[(par * 2 + 0) * n + sq] : smx[d], omn = sq >= 0 ? cur[(par * 2 + 1) * n + sq] : smn[d];
+                mx = omx > mx ? omx : mx;
+                mn = omn < mn ? omn : mn;
+                const long long node = anc(ti, D, d);
+                P.maxt[node] = mx; P.mint[node] = mn;
+            }
+            if (d > 0 && ((readers >> (d - 1)) & 1u)) {              // the next level has readers: publish this level's values
+                par ^= 1;
+                if (active) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
+                level_sync();
+            }
+        }
+    }
+}
+
 __device__ void per_apply_updates(const ReplayParams &P, unsigned char *smem, int n, int tid, int nthreads) {
     const UpdLayout Lo(n);
     double (*val)[MAXH] = reinterpret_cast<double (*)[MAXH]>(smem + Lo.val);
@@ -274,14 +320,18 @@ __device__ void per_apply_updates(const ReplayParams &P, unsigned char *smem, in
         val[j][d] = v;
     }
     // (the heaps' pre-loads: thread j's off-path children, every level, requested now and used after the walk)
+    // (n <= 64: the heap threads are the first n of wave 1, so that they can climb while wave 0 walks; longer lists: threads 0 .. n - 1)
+    const bool hfast = n <= 64 && nthreads >= 128;
+    const int hj = hfast ? tid - 64 : tid;
+    const bool hact = hj >= 0 && hj < n;
     double smx[MAXH - 1], smn[MAXH - 1];
     {
-        const int j = tid < n ? tid : 0;
+        const int j = hact ? hj : 0;
         const long long ti = ti_s[j];
         const int D = node_depth(ti);
 #pragma unroll
         for (int d = 0; d < MAXH - 1; d++) {
-            const bool need = tid < n && d < D && sib[j][d] < 0;
+            const bool need = hact && d < D && sib[j][d] < 0;
             const long long on = d < D ? anc(ti, D, d + 1) : 1;          // j's node at depth d + 1; its sibling is the other child of the parent
             const long long off = need ? (((on + 1) ^ 1) - 1) : 0;
             smx[d] = P.maxt[off]; smn[d] = P.mint[off];
@@ -318,6 +368,9 @@ __device__ void per_apply_updates(const ReplayParams &P, unsigned char *smem, in
             }
         }
     }
+    // (n <= 64) 4) the heaps, in wave 1, BESIDE the walk: they need the links and the final leaf values, not the sums
+    if (hfast && tid >= 64 && tid < 128)
+        per_heaps<true>(P, n, hact, hact ? hj : 0, ti_s, p_s, rep_s, sib, *sibmask, cur, smx, smn);
     __syncthreads();
     if (PU_EXIT == 4) { if (smx[3] == 1.2345 && smn[7] == 2.5) P.dev->error = 7; return; }
     // 3) write back: the last occurrence of every touched node
@@ -327,46 +380,8 @@ __device__ void per_apply_updates(const ReplayParams &P, unsigned char *smem, in
         const int D = node_depth(ti);
         if (d <= D && ((lastm[j] >> d) & 1u)) P.tree[anc(ti, D, d)] = val[j][d];
     }
-    // 4) max / min heaps: thread j climbs from its leaf (the LAST occurrence's p: later duplicates win) to the root
-    {
-        const int j = tid < n ? tid : 0;
-        const long long ti = ti_s[j];
-        const int D = node_depth(ti);
-        // the leaf's final value: p of the last entry with this leaf (later duplicates win)
-        double mx = p_s[rep_s[j]], mn = mx;
-        if (tid < n) { P.maxt[ti] = mx; P.mint[ti] = mn; }
-        const int Dtop = node_depth(2 * P.cap - 2);                      // the deeper leaf level: the loop below is uniform over the block
-        const unsigned readers = *sibmask;
-        // Entries exchange values only at levels where some sibling subtree is touched as well (`readers`: for a random batch in a big tree
-        // that is the top few levels): a level with readers is fed by an LDS write + ONE barrier at the end of the level below it; the
-        // other levels are thread-local.  (The barrier waits for LDS traffic only: __syncthreads() would also drain the global stores of
-        // every level -- nobody in this workgroup reads them -- one store round trip per level.)
-        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-        int par = 0;
-        const int dfirst = Dtop - 1;
-        if (dfirst >= 0 && ((readers >> dfirst) & 1u)) {                 // (uniform)
-            if (tid < n) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
-            lds_barrier();
-        }
-#pragma unroll
-        for (int d = MAXH - 2; d >= 0; d--) {
-            if (d < Dtop) {                                              // (uniform)
-                if (tid < n && d < D) {
-                    const int sq = sib[j][d];
-                    const double omx = sq >= 0 ? cur[(par * 2 + 0) * n + sq] : smx[d], omn = sq >= 0 ? cur[(par * 2 + 1) * n + sq] : smn[d];
-                    mx = omx > mx ? omx : mx;
-                    mn = omn < mn ? omn : mn;
-                    const long long node = anc(ti, D, d);
-                    P.maxt[node] = mx; P.mint[node] = mn;
-                }
-                if (d > 0 && ((readers >> (d - 1)) & 1u)) {              // the next level has readers: publish this level's values
-                    par ^= 1;
-                    if (tid < n) { cur[(par * 2 + 0) * n + j] = mx; cur[(par * 2 + 1) * n + j] = mn; }
-                    lds_barrier();
-                }
-            }
-        }
-    }
+    // (longer lists) 4) the heaps, all waves
+    if (!hfast) per_heaps<false>(P, n, hact, hact ? hj : 0, ti_s, p_s, rep_s, sib, *sibmask, cur, smx, smn);
 }
 
 // Memory.store for `count` new transitions (BrainPrioritizedReplyDQN.py:121-125, add :50-60), reference order, parallel over
