@@ -69,7 +69,7 @@ class OverlappedAllReduce:
 
     OPT-IN (FB_DP_OVERLAP=1), not the default: through torch.distributed every collective costs two cross-stream hops (step stream ->
     RCCL's stream -> back), the event and the join add two more, and at world size 1 -- where RCCL's all-reduce is a copy -- the split
-    step measures 31 us SLOWER than the plain one (172 vs 141 us; fused single-GPU step 131).  It can only pay where the 3.3 MB
+    step measures 27 us SLOWER than the plain one (152 vs 125 us; fused single-GPU step 114).  It can only pay where the 3.3 MB
     all-reduce itself takes longer than that, which no hardware available to this build could show."""
 
     def __init__(self, net, flat_grad, mean_loss, force=False):
