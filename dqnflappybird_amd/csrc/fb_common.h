@@ -110,9 +110,13 @@ int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own wo
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                           uint8_t *actions, FbHeadRider *head, void *stream);
-// the rider for "fb_replay_push" of a uniform memory (returns 1, fills *push and COUNTS the push: the env launch that
-// carries it must follow), 0 for a prioritized memory (its tree update needs its own launches)
+// the rider for the frame / scalar part of "fb_replay_push" (returns 1, fills *push and COUNTS the push: the env launch that carries it
+// must follow, and fb_replay_finish_push behind that launch: Memory.store's tree update of a prioritized memory -- joined if it ran
+// ahead on the side stream, launched otherwise; nothing for a uniform memory)
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push);
+int fb_replay_finish_push(fb_replay_t h, void *stream);
+// fb_replay_sample that also leaves the importance weights as float32 (the loss's placeholder type), or NULL
+int fb_replay_sample_f32(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, float *isw32, void *stream);
 // the rider for "fb_replay_push; fb_replay_sample(batch) -> idx" (memory as it will be after `pushes_ahead` more pushes).  Returns 1 and
 // fills *rider for a uniform memory with the CPython generator, 0 when the sampler cannot ride (PER, other generators).
 int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider *rider, int pushes_ahead = 1);

@@ -134,10 +134,6 @@ extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int b
     return rc;
 }
 
-__global__ void f64_to_f32_kernel(const double *__restrict__ x, float *__restrict__ y, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = (float)x[i];      // (what feeding float64 ISWeights to a float32 placeholder does)
-}
-
 // One step of the vectorised loop as a single host call: the five C-ABI calls of FlappyBirdDQN.py:72-76 back to back.
 extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
                            int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream) {
@@ -183,14 +179,16 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     if (!have_p) {
         if (train && !have_s && !per) rc = fb_replay_push_sample(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, batch, b->idx, stream);
         else rc = fb_replay_push(replay, nullptr, b->frame_bits, b->actions, b->reward, b->terminal, stream);
-    } else if (train && !have_s && !per) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
+    } else {
+        rc = fb_replay_finish_push(replay, stream);      // (prioritized memory: the tree part of the push the env launch carried)
+        if (rc == FB_OK && train && !have_s && !per) rc = fb_replay_sample(replay, batch, nullptr, b->idx, nullptr, stream);
+    }
     if (rc != FB_OK || !train) return rc;
     if (per) {
         // BrainPrioritizedReplyDQN.py:277-329 from the sample on: importance weights -> weighted loss -> |TD errors| back into the tree
         // (fb_replay_sample above wrote the tree indices; its weights come as f64, the loss takes them as the float32 placeholder did)
-        rc = fb_replay_sample(replay, batch, nullptr, b->idx, b->isw, stream);
+        rc = fb_replay_sample_f32(replay, batch, nullptr, b->idx, b->isw, b->isw32, stream);
         if (rc != FB_OK) return rc;
-        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(256), 0, fb_stream(stream), (const double *)b->isw, b->isw32, batch);
         if (n_envs >= 256) {
             FbRingSrc ring;
             rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);

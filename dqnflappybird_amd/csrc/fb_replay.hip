@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, 
 // Memory.sample (BrainPrioritizedReplyDQN.py:127-144)
 __global__ __launch_bounds__(256) void per_sample_kernel(ReplayParams P, int n, const double *__restrict__ uni,
                                                          long long *__restrict__ idx_out,
-                                                         double *__restrict__ isw_out) {
+                                                         double *__restrict__ isw_out, float *__restrict__ isw32_out) {
     __shared__ uint32_t mt[624];
     __shared__ uint32_t words[2 * MAXB];
     const int tid = threadIdx.x;
@@ -701,7 +701,9 @@ __global__ __launch_bounds__(256) void per_sample_kernel(ReplayParams P, int n, 
         const double prob = P.tree[parent] / total;
         const double min_prob = P.mint[0] / total;               // get_min_prob over the filled leaves
         idx_out[tid] = parent;
-        isw_out[tid] = pow(prob / min_prob, -beta);
+        const double wgt = pow(prob / min_prob, -beta);
+        isw_out[tid] = wgt;
+        if (isw32_out) isw32_out[tid] = (float)wgt;               // (the float32 ISWeights placeholder of the loss, :245)
     }
     if (tid == 0) { P.dev->beta = beta; P.dev->philox_calls = call + 1; }
 }
@@ -837,6 +839,14 @@ extern "C" int fb_replay_push(fb_replay_t h, const uint8_t *frames, const uint64
                        actions, rewards, terminals);
     FB_LAUNCH_CHECK();
     h->host_steps += 1;
+    return fb_replay_finish_push(h, stream);
+}
+
+// Memory.store's tree part of a push whose frames and scalars are on their way (push_kernel above, or the env launch that carried them:
+// fb_replay_begin_push_rider).  Uniform memory: nothing to do.
+int fb_replay_finish_push(fb_replay_t h, void *stream) {
+    ReplayParams &P = h->P;
+    hipStream_t st = fb_stream(stream);
     if (P.kind == FB_REPLAY_PER) {
         if (h->store_ahead) {                    // the tree part ran ahead on the side stream: whatever follows this push waits for it
             h->store_ahead = false;
@@ -899,7 +909,6 @@ int fb_replay_is_prioritized(fb_replay_t h) { return h && h->P.kind == FB_REPLAY
 
 int fb_replay_begin_push_rider(fb_replay_t h, FbPushRider *push) {
     ReplayParams &P = h->P;
-    if (P.kind != FB_REPLAY_UNIFORM) return 0;
     const long long steps = h->host_steps;               // push_kernel: frame steps + 1, meta row steps
     push->bits = P.bits + (size_t)((steps + 1) % P.t_f) * P.n_envs * WORDS;
     const size_t mo = (size_t)(steps % P.t_f) * P.n_envs;
@@ -938,13 +947,17 @@ extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *str
 }
 
 extern "C" int fb_replay_sample(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, void *stream) {
+    return fb_replay_sample_f32(h, batch, uniforms, idx, isw, nullptr, stream);
+}
+
+int fb_replay_sample_f32(fb_replay_t h, int batch, const double *uniforms, int64_t *idx, double *isw, float *isw32, void *stream) {
     FB_REQUIRE(h && idx, "fb_replay_sample: NULL argument");
     FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_sample: batch must be in 1..%d", MAXB);
     ReplayParams &P = h->P;
     hipStream_t st = fb_stream(stream);
     if (P.kind == FB_REPLAY_PER) {
         FB_REQUIRE(isw, "fb_replay_sample: PER needs isw");
-        hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, st, P, batch, uniforms, (long long *)idx, isw);
+        hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, st, P, batch, uniforms, (long long *)idx, isw, isw32);
     } else if (P.rng_kind == FB_RNG_PHILOX) {
         hipLaunchKernelGGL(sample_philox_kernel, dim3(1), dim3(256), 0, st, P, batch, (long long *)idx);
     } else {
