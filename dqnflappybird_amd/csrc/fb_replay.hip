@@ -619,9 +619,11 @@ __global__ __launch_bounds__(256) void per_update_fast_kernel(ReplayParams P, in
 }
 
 // Memory.batch_update (BrainPrioritizedReplyDQN.py:146-151)
+// write_back = 0: the caller's abs_err array is left alone (the run-ahead form: the kernel runs on the memory's side stream while the
+// caller's stream may be reading that array)
 __global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, const long long *__restrict__ idx,
                                                          float *__restrict__ abs_err,
-                                                         const float *__restrict__ prio) {
+                                                         const float *__restrict__ prio, int write_back) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const UpdLayout Lo(n);
     long long *ti_w = reinterpret_cast<long long *>(smem + Lo.ti);
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void per_update_kernel(ReplayParams P, int n, 
         if (prio) ps = prio[j];
         else {
             float e = abs_err[j] + 0.01f;                        // abs_errors += epsilon (in place, fp32)
-            abs_err[j] = e;
+            if (write_back) abs_err[j] = e;
             const float c = e < 1.0f ? e : 1.0f;                 // np.minimum(.., abs_err_upper)
             ps = (float)pow((double)c, (double)0.6f);            // np.power(fp32, 0.6) -> fp32
         }
@@ -718,9 +720,19 @@ struct fb_replay {
     // prioritized memories: Memory.store's TREE part of the coming push can run ahead of it on a stream of its own
     // (fb_replay_per_store_ahead): it needs the tree and the number of envs, nothing of the frames
     hipStream_t side;
-    hipEvent_t ev_fork, ev_store;
+    hipEvent_t ev_fork, ev_store, ev_upd;
     bool store_ahead;                // the tree part of the next fb_replay_push has been issued already; that push joins it
+    bool upd_pending;                // a batch_update runs on the side stream (fb_replay_update_priorities_ahead): whatever touches the tree next joins it
 };
+
+// every entry point that reads or writes the tree on a caller's stream passes here first
+static int per_join(fb_replay *h, hipStream_t st) {
+    if (h->upd_pending) {
+        FB_CHECK_HIP(hipStreamWaitEvent(st, h->ev_upd, 0));
+        h->upd_pending = false;
+    }
+    return FB_OK;
+}
 
 extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_replay_t *out) {
     FB_REQUIRE(out, "fb_replay_create: out is NULL");
@@ -764,7 +776,8 @@ extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_repla
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_store, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&h->ev_store, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess) {
             fb_set_error(FB_ERR_HIP, "fb_replay_create: stream / event creation failed");
             fb_replay_destroy(h);
             return FB_ERR_HIP;
@@ -784,6 +797,7 @@ extern "C" int fb_replay_destroy(fb_replay_t h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_store) (void)hipEventDestroy(h->ev_store);
+    if (h->ev_upd) (void)hipEventDestroy(h->ev_upd);
     delete h;
     return FB_OK;
 }
@@ -810,6 +824,10 @@ extern "C" int fb_replay_reset(fb_replay_t h, const uint8_t *frames, const uint6
     ReplayParams &P = h->P;
     hipStream_t st = fb_stream(stream);
     if (P.kind == FB_REPLAY_PER) {
+        if (h->side) {                   // (nothing of an earlier life may still be on its way to the tree)
+            FB_CHECK_HIP(hipStreamSynchronize(h->side));
+            h->store_ahead = false; h->upd_pending = false;
+        }
         const long long nn = 2 * P.cap - 1;
         FB_CHECK_HIP(hipMemsetAsync(P.tree, 0, sizeof(double) * nn, st));
         FB_CHECK_HIP(hipMemsetAsync(P.maxt, 0, sizeof(double) * nn, st));
@@ -850,9 +868,12 @@ int fb_replay_finish_push(fb_replay_t h, void *stream) {
     if (P.kind == FB_REPLAY_PER) {
         if (h->store_ahead) {                    // the tree part ran ahead on the side stream: whatever follows this push waits for it
             h->store_ahead = false;
+            h->upd_pending = false;              // (a batch_update in front of it on that stream is covered by the same wait)
             FB_CHECK_HIP(hipStreamWaitEvent(st, h->ev_store, 0));
             return FB_OK;
         }
+        const int rcj = per_join(h, st);
+        if (rcj != FB_OK) return rcj;
         if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
         else hipLaunchKernelGGL(per_store_kernel, dim3(1), dim3(1024), 0, st, P, P.n_envs);
         FB_LAUNCH_CHECK();
@@ -869,7 +890,9 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
     // (reference-order mode only: the level-wise FB_PER_FAST store takes ~8 us, less than the two cross-stream hops cost)
     if (!h || h->P.kind != FB_REPLAY_PER || h->store_ahead || h->per_mode == FB_PER_FAST) return 0;
     hipStream_t st = fb_stream(stream);
-    if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;
+    // (behind a run-ahead batch_update the side stream is already ordered after the caller's last touch of the tree -- that update's own
+    // fork -- and nothing on the caller's stream has touched the tree since: no second fork)
+    if (!h->upd_pending && (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess)) return 0;
     if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
     else hipLaunchKernelGGL(per_store_slim_kernel, dim3(1), dim3(256), 0, h->side, h->P, h->P.n_envs);     // (the shape that fits beside the acting trunk)
     if (hipEventRecord(h->ev_store, h->side) != hipSuccess) { (void)hipStreamWaitEvent(st, h->ev_fork, 0); return 0; }
@@ -957,6 +980,8 @@ int fb_replay_sample_f32(fb_replay_t h, int batch, const double *uniforms, int64
     hipStream_t st = fb_stream(stream);
     if (P.kind == FB_REPLAY_PER) {
         FB_REQUIRE(isw, "fb_replay_sample: PER needs isw");
+        const int rcj = per_join(h, st);
+        if (rcj != FB_OK) return rcj;
         hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, st, P, batch, uniforms, (long long *)idx, isw, isw32);
     } else if (P.rng_kind == FB_RNG_PHILOX) {
         hipLaunchKernelGGL(sample_philox_kernel, dim3(1), dim3(256), 0, st, P, batch, (long long *)idx);
@@ -997,26 +1022,52 @@ extern "C" int fb_replay_profile_gather(fb_replay_t h, int batch, const int64_t 
     return FB_OK;
 }
 
+static int launch_per_update(fb_replay *h, int batch, const int64_t *idx, float *abs_err, const float *prio, int write_back, hipStream_t st) {
+    const size_t bytes = (size_t)UpdLayout(batch).bytes;                 // 10 KB at a batch of 32, 150 KB at 256
+    static size_t allowed = 48 * 1024;                                   // (dynamic LDS beyond the default limit has to be asked for, once)
+    if (bytes > allowed) {
+        FB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(per_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        allowed = bytes;
+    }
+    hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), bytes, st, h->P, batch, (const long long *)idx, abs_err, prio, write_back);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
 extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64_t *idx, float *abs_err,
                                            const float *priorities_or_null, void *stream) {
     FB_REQUIRE(h && idx && (abs_err || priorities_or_null), "fb_replay_update_priorities: NULL argument");
     FB_REQUIRE(h->P.kind == FB_REPLAY_PER, "fb_replay_update_priorities: not a prioritized memory");
     FB_REQUIRE(batch >= 1 && batch <= MAXB, "fb_replay_update_priorities: batch must be in 1..%d", MAXB);
-    if (h->per_mode == FB_PER_FAST)
+    const int rcj = per_join(h, fb_stream(stream));
+    if (rcj != FB_OK) return rcj;
+    if (h->per_mode == FB_PER_FAST) {
         hipLaunchKernelGGL(per_update_fast_kernel, dim3(1), dim3(256), 0, fb_stream(stream), h->P, batch, (const long long *)idx, abs_err,
                            priorities_or_null);
-    else {
-        const size_t bytes = (size_t)UpdLayout(batch).bytes;                 // 10 KB at a batch of 32, 150 KB at 256
-        static size_t allowed = 48 * 1024;                                   // (dynamic LDS beyond the default limit has to be asked for, once)
-        if (bytes > allowed) {
-            FB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(per_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            allowed = bytes;
-        }
-        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), bytes, fb_stream(stream), h->P, batch,
-                           (const long long *)idx, abs_err, priorities_or_null);
+        FB_LAUNCH_CHECK();
+        return FB_OK;
     }
-    FB_LAUNCH_CHECK();
-    return FB_OK;
+    return launch_per_update(h, batch, idx, abs_err, priorities_or_null, 1, fb_stream(stream));
+}
+
+// Memory.batch_update on the memory's SIDE stream, behind everything `stream` holds so far (reference-order mode; returns 1 when issued,
+// 0 when the caller has to make the ordinary call).  What follows batch_update in the loop -- the next step's acting forward and env
+// step -- does not touch the tree; the next thing that does is Memory.store of the next step, which fb_replay_per_store_ahead puts on the
+// same stream right behind this, and the push / sample that follow join that.  The kernel (17.6 us at a batch of 32, one workgroup)
+// leaves the critical path; abs_err is read, not written (the in-place `abs_errors += epsilon` of :147 stays inside the kernel).
+int fb_replay_update_priorities_ahead(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream) {
+    static const bool on = !(getenv("FB_PER_UPDATE_AHEAD") && atoi(getenv("FB_PER_UPDATE_AHEAD")) == 0);      // A/B knob
+    if (!on || !h || h->P.kind != FB_REPLAY_PER || h->per_mode != FB_PER_EXACT || !h->side || !idx || !abs_err || batch < 1 || batch > MAXB) return 0;
+    if (h->store_ahead || h->upd_pending) return 0;                        // (not in the loop's order: take the ordinary path)
+    hipStream_t st = fb_stream(stream);
+    if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;
+    if (launch_per_update(h, batch, idx, const_cast<float *>(abs_err), nullptr, 0, h->side) != FB_OK ||
+        hipEventRecord(h->ev_upd, h->side) != hipSuccess) {
+        (void)hipStreamSynchronize(h->side);                               // whatever did get issued is done before anyone goes on
+        return 0;
+    }
+    h->upd_pending = true;
+    return 1;
 }
 
 extern "C" int fb_replay_set_per_mode(fb_replay_t h, int mode) {

@@ -6,12 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
 n, B = int(os.environ.get("FB_TRACE_ENVS", "1024")), int(os.environ.get("FB_TRACE_BATCH", "32"))
-env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n), QNet(max_batch=n)
-replay.seed(0, "cpython")
+algo = os.environ.get("FB_TRACE_ALGO", "dqn")                  # "per": prioritized memory (reference-order tree), the loop of configs[3]
+env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n, prioritized=algo == "per"), QNet(max_batch=n)
+replay.seed(0, "numpy" if algo == "per" else "cpython")
 net.init_params(0)
 nib = env.track_state()
 env.observe(); replay.reset(env.frame_bits)
-one = VecStep(env, replay, net, B, "dqn")
+one = VecStep(env, replay, net, B, algo)
 train = os.environ.get("FB_TRACE_TRAIN", "1") == "1"          # 0: act -> env -> push only (W_fc1's planes never go stale)
 for step in range(150):
     one(0.03, seed=0, step=step, train=train)
