@@ -156,7 +156,9 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // prioritized memory: Memory.store's tree update of this step's push goes out FIRST, on the memory's side stream -- it depends on the
     // tree as the previous step left it and on the env count, nothing else -- and runs beside the acting forward and the env step
     static const bool store_ahead = !(getenv("FB_PER_STORE_AHEAD") && atoi(getenv("FB_PER_STORE_AHEAD")) == 0);      // A/B knob
-    if (per && store_ahead) (void)fb_replay_per_store_ahead(replay, stream);
+    int sampled = 0;                                 // ... and, behind it on that stream, Memory.sample of this step (it needs that tree and the memory's generator)
+    if (per && store_ahead && fb_replay_per_store_ahead(replay, stream) && train)
+        sampled = fb_replay_sample_ahead(replay, batch, b->idx, b->isw, b->isw32);
     // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
     // every env has a workgroup of its own there
     FbHeadRider hrider;
@@ -187,7 +189,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     if (per) {
         // BrainPrioritizedReplyDQN.py:277-329 from the sample on: importance weights -> weighted loss -> |TD errors| back into the tree
         // (fb_replay_sample above wrote the tree indices; its weights come as f64, the loss takes them as the float32 placeholder did)
-        rc = fb_replay_sample_f32(replay, batch, nullptr, b->idx, b->isw, b->isw32, stream);
+        if (!sampled) rc = fb_replay_sample_f32(replay, batch, nullptr, b->idx, b->isw, b->isw32, stream);      // (else: joined with the push)
         if (rc != FB_OK) return rc;
         if (n_envs >= 256) {
             FbRingSrc ring;

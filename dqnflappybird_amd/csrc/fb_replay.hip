@@ -900,6 +900,20 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
     return 1;
 }
 
+// Memory.sample of the step whose Memory.store has just been put on the side stream (fb_replay_per_store_ahead returned 1): the draw needs
+// the tree as that store leaves it and the memory's own generator -- nothing of the env step -- so it follows the store there and the
+// push's join covers it (ev_store is recorded again behind it).  Returns 1 when issued.
+int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32) {
+    static const bool on = !(getenv("FB_PER_SAMPLE_AHEAD") && atoi(getenv("FB_PER_SAMPLE_AHEAD")) == 0);      // A/B knob
+    if (!on || !h || h->P.kind != FB_REPLAY_PER || !h->store_ahead || !idx || !isw || batch < 1 || batch > MAXB) return 0;
+    hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, h->side, h->P, batch, (const double *)nullptr, (long long *)idx, isw, isw32);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(h->ev_store, h->side) != hipSuccess) {
+        (void)hipStreamSynchronize(h->side);                 // (the store's own record stands; whatever was issued is done before anyone goes on)
+        return 0;
+    }
+    return 1;
+}
+
 static long long cpython_setsize(int batch) {
     // Lib/random.py: setsize = 21; if k > 5: setsize += 4 ** _ceil(_log(k * 3, 4))
     long long setsize = 21;
