@@ -1070,8 +1070,13 @@ extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64
 // same stream right behind this, and the push / sample that follow join that.  The kernel (17.6 us at a batch of 32, one workgroup)
 // leaves the critical path; abs_err is read, not written (the in-place `abs_errors += epsilon` of :147 stays inside the kernel).
 int fb_replay_update_priorities_ahead(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream) {
-    static const bool on = !(getenv("FB_PER_UPDATE_AHEAD") && atoi(getenv("FB_PER_UPDATE_AHEAD")) == 0);      // A/B knob
-    if (!on || !h || h->P.kind != FB_REPLAY_PER || h->per_mode != FB_PER_EXACT || !h->side || !idx || !abs_err || batch < 1 || batch > MAXB) return 0;
+    // Only where the acting phase it hides behind is long enough: the kernel (139 registers per lane) cannot share a CU with a workgroup of
+    // the acting trunk (2 waves x 224 registers per SIMD), so it starts when the trunk's first round of workgroups retires -- 30 us in --
+    // and at 1024 / 2048 envs (one / two rounds) the side stream then finishes AFTER the env step: measured 185 / 206 us per step against
+    // 164 / 196 in line; at 4096 envs (four rounds) 272 against 286.  FB_PER_UPDATE_AHEAD=0 / 1 forces the in-line / run-ahead form.
+    static const int knob = getenv("FB_PER_UPDATE_AHEAD") ? atoi(getenv("FB_PER_UPDATE_AHEAD")) : -1;
+    if (knob == 0 || !h || h->P.kind != FB_REPLAY_PER || h->per_mode != FB_PER_EXACT || !h->side || !idx || !abs_err || batch < 1 || batch > MAXB) return 0;
+    if (knob < 0 && h->P.n_envs < 4096) return 0;
     if (h->store_ahead || h->upd_pending) return 0;                        // (not in the loop's order: take the ordinary path)
     hipStream_t st = fb_stream(stream);
     if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;

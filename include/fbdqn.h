@@ -323,7 +323,7 @@ typedef struct {
     float *flat_grad;                               /* f32[n_params] or NULL */
     /* prioritized replay (algo = FB_ALGO_PER) only, else NULL: Memory.sample's importance weights as it returns them (f64[B]) and as the
      * float32 placeholder takes them (f32[B]), and the |TD errors| Memory.batch_update receives (f32[B]).
-     * With the reference-order tree Memory.batch_update of a step runs on the memory's own side stream, beside the NEXT step's acting
+     * With the reference-order tree and 4096 envs or more Memory.batch_update of a step runs on the memory's own side stream, beside the NEXT step's acting
      * forward (its result is first needed by that step's Memory.store, which follows it there): idx and abs_err are read after
      * fb_vec_step has returned and must stay valid -- and unwritten by the caller -- until the next call on this memory; abs_err then
      * holds |TD error| as the loss left it (fb_replay_update_priorities, the stand-alone call, adds its 0.01 in place as the

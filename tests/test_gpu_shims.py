@@ -422,17 +422,18 @@ def test_vec_step_data_parallel_path_equals_fused(torch_cuda, N, steps, algo):
     assert p1[0] < 0.9 ** (steps - 8)                                    # and the optimizer really stepped steps - 8 times
 
 
-@pytest.mark.parametrize("dp", [False, True])
-def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda, dp):
+@pytest.mark.parametrize("dp,N,steps", [(False, 256, 30), (True, 256, 30), (False, 4096, 14)])
+def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda, dp, N, steps):
     """fb_vec_step on a prioritized memory (BrainPrioritizedReplyDQN.py:277-329 for N envs in one host call: act -> env -> Memory.store ->
     Memory.sample -> weighted train -> Memory.batch_update) == the separate calls, bit for bit: actions, tree indices, importance
     weights, loss and |TD errors| step by step, parameters, the raw tree bytes and beta at the end (reference-order tree)."""
     torch = torch_cuda
     from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep, train_from_replay
-    N, B, steps = 256, 32, 30
+    # (4096 envs: Memory.batch_update runs ahead on the memory's side stream as well -- from that env count on it is the default)
+    B = 32
 
     def make():
-        env, rep, net = VecGameState(N, seed=5), VecReplay(8192, N, prioritized=True), QNet(max_batch=N)
+        env, rep, net = VecGameState(N, seed=5), VecReplay(32 * N, N, prioritized=True), QNet(max_batch=N)
         rep.seed(9, "numpy"); net.init_params(3, which=0); net.init_params(4, which=1)
         nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
         return env, rep, net, nib
