@@ -84,11 +84,34 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
                 }
             }
         }
+        // The general loop, a window of up to 64 words at a time.  A window whose candidates below n clash neither with each other nor
+        // with what is selected already (all but ~k^2 / n of the draws) is taken WHOLE, in stream order: rank by ballot, one LDS write per
+        // candidate into pool[] (the selection so far, in order: every lane reads it back as broadcasts for the next window's test),
+        // then every lane re-reads its register slots.  Only a window with a clash is walked word by word.  (k = 256 from a million
+        // slots: ~25 us of dependent per-word iterations -> ~3; as a rider this chain was the longest of the env launch.)
         while (i < k) {
             if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
             const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
             const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
-            unsigned long long mask = __ballot(lane < take && w < (uint32_t)n);
+            const bool valid = lane < take && w < (uint32_t)n;
+            unsigned long long mask = __ballot(valid);
+            if (n < (1ll << 31)) {                                   // (the sentinels below are told from values by bit 31)
+                bool clash = false;
+                for (int t = 0; t < i; t++) clash |= (uint32_t)pool[t] == w;
+                clash &= valid;
+                const uint32_t c = valid ? w : (0x80000000u | (uint32_t)lane);
+                for (int d = 1; d < 64; d++) clash |= (uint32_t)__shfl((int)c, (lane + d) & 63) == c;
+                if (!__any(clash)) {
+                    const int need = k - i, m = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    if (valid && rank < need) pool[i + rank] = (int)w;
+                    if (m >= need) { idx += __builtin_ctzll(__ballot(valid && rank == need - 1)) + 1; i = k; }      // up to and including the k-th
+                    else { idx += take; i += m; }
+                    __builtin_amdgcn_wave_barrier();            // one wave: LDS executes its writes before its reads; this pins the order
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sel[q] = q * 64 + lane < i ? (long long)pool[q * 64 + lane] : -1;
+                    continue;
+                }
+            }
             int consumed = take;
             while (mask) {
                 const int l = __builtin_ctzll(mask);
@@ -99,8 +122,10 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
                 for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
                 if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
                 set_sel(sel, i, lane, c);
+                if (lane == 0) pool[i] = (int)c;
                 if (++i == k) { consumed = l + 1; break; }
             }
+            __builtin_amdgcn_wave_barrier();
             idx += consumed;
         }
     } else {
