@@ -126,7 +126,7 @@ __device__ __forceinline__ FbSampleCtx sample_ctx(const ReplayParams &P, long lo
 __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int k, long long setsize,
                                                             long long *__restrict__ out) {
     __shared__ uint32_t mt[624];
-    __shared__ int pool[1100];
+    __shared__ int pool[FB_SAMPLE_POOL + FB_SAMPLE_TAB];
     sample_cpython_body(sample_ctx(P, P.dev->steps), k, setsize, out, mt, pool);
 }
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void push_sample_kernel(ReplayParams P, long lo
                                                          const uint8_t *__restrict__ t, int k, long long setsize,
                                                          long long *__restrict__ out) {
     __shared__ uint32_t mt[624];
-    __shared__ int pool[1100];
+    __shared__ int pool[FB_SAMPLE_POOL + FB_SAMPLE_TAB];
     if (blockIdx.x == gridDim.x - 1) { sample_cpython_body(sample_ctx(P, steps + 1), k, setsize, out, mt, pool); return; }
     const int lane = threadIdx.x;
     for (int e = blockIdx.x; e < P.n_envs; e += gridDim.x - 1) {

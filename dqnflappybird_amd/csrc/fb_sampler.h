@@ -5,7 +5,8 @@
 #pragma once
 
 constexpr int FB_SAMPLE_MAXB = 256;          // indices per draw (4 register slots x 64 lanes)
-constexpr int FB_SAMPLE_LDS_WORDS = 624 + 1100;      // mt[624] + pool[1100]
+constexpr int FB_SAMPLE_POOL = 1100, FB_SAMPLE_TAB = 1024;   // pool[]: the shrinking population (n <= setsize) / the selection in order; tab[]: the `selected` set
+constexpr int FB_SAMPLE_LDS_WORDS = 624 + FB_SAMPLE_POOL + FB_SAMPLE_TAB;      // mt[624] + pool[] + tab[] (pool points at the last two)
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
@@ -84,49 +85,69 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
                 }
             }
         }
-        // The general loop, a window of up to 64 words at a time.  A window whose candidates below n clash neither with each other nor
-        // with what is selected already (all but ~k^2 / n of the draws) is taken WHOLE, in stream order: rank by ballot, one LDS write per
-        // candidate into pool[] (the selection so far, in order: every lane reads it back as broadcasts for the next window's test),
-        // then every lane re-reads its register slots.  Only a window with a clash is walked word by word.  (k = 256 from a million
-        // slots: ~25 us of dependent per-word iterations -> ~3; as a rider this chain was the longest of the env launch.)
+        // The general loop, a window of up to 64 words at a time.  CPython's `selected` set is a hash table in LDS (tab[]: open addressing,
+        // 1024 slots for at most 256 + 64 values): every candidate below n of the window is inserted with one compare-and-swap chain, and
+        // an insert that finds its own value there is a clash -- with an earlier window or inside this one.  A window without a clash
+        // (all but ~k^2 / n of the draws) is taken WHOLE, in stream order: rank by ballot, one LDS write per candidate into pool[] (the
+        // selection in order).  A window with a clash takes its inserts back (every lane clears the slot it filled: the table is as the
+        // windows before left it) and is walked word by word, one lane inserting.  (k = 256 from a million slots: ~25 us of dependent
+        // per-word iterations; an all-pairs register test per window still ~15 -- the five-compare, 63-rotation test is ~2 us of issue
+        // per window; as a rider this chain was the longest of the env launch.)
+        int *tab = pool + FB_SAMPLE_POOL;
+        const bool looped = i < k;
+        if (looped) for (int t = lane; t < FB_SAMPLE_TAB; t += 64) tab[t] = -1;
+        __builtin_amdgcn_wave_barrier();
+        auto insert = [&](uint32_t v, int &slot) {               // true: v was there already
+            uint32_t hsh = (v * 2654435761u) >> 22;
+            for (;;) {
+                const int old = atomicCAS(&tab[hsh], -1, (int)v);
+                if (old == -1) { slot = (int)hsh; return false; }
+                if (old == (int)v) return true;
+                hsh = (hsh + 1) & (FB_SAMPLE_TAB - 1);
+            }
+        };
         while (i < k) {
             if (idx >= 624) { mt_regen(mt, lane); idx = 0; regenerated = true; }
             const int avail = 624 - (int)idx, take = avail < 64 ? avail : 64;
             const uint32_t w = lane < take ? mt_temper(mt[idx + lane]) >> shift : 0xFFFFFFFFu;
             const bool valid = lane < take && w < (uint32_t)n;
             unsigned long long mask = __ballot(valid);
-            if (n < (1ll << 31)) {                                   // (the sentinels below are told from values by bit 31)
-                bool clash = false;
-                for (int t = 0; t < i; t++) clash |= (uint32_t)pool[t] == w;
-                clash &= valid;
-                const uint32_t c = valid ? w : (0x80000000u | (uint32_t)lane);
-                for (int d = 1; d < 64; d++) clash |= (uint32_t)__shfl((int)c, (lane + d) & 63) == c;
+            if (n < (1ll << 31)) {                                   // (values are stored as non-negative ints, -1 = empty)
+                int slot = -1;
+                const bool clash = valid && insert(w, slot);
                 if (!__any(clash)) {
                     const int need = k - i, m = __popcll(mask), rank = __popcll(mask & ((1ull << lane) - 1ull));
                     if (valid && rank < need) pool[i + rank] = (int)w;
                     if (m >= need) { idx += __builtin_ctzll(__ballot(valid && rank == need - 1)) + 1; i = k; }      // up to and including the k-th
                     else { idx += take; i += m; }
-                    __builtin_amdgcn_wave_barrier();            // one wave: LDS executes its writes before its reads; this pins the order
-#pragma unroll
-                    for (int q = 0; q < 4; q++) sel[q] = q * 64 + lane < i ? (long long)pool[q * 64 + lane] : -1;
                     continue;
                 }
+                if (slot >= 0) tab[slot] = -1;
+                __builtin_amdgcn_wave_barrier();
             }
             int consumed = take;
             while (mask) {
                 const int l = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const long long c = (long long)__shfl(w, l);
-                bool dup = false;
-#pragma unroll
-                for (int q = 0; q < 4; q++) dup |= (sel[q] == c);
-                if (__any(dup)) continue;               // `while j in selected: j = randbelow(n)`
-                set_sel(sel, i, lane, c);
+                const uint32_t c = (uint32_t)__shfl((int)w, l);
+                int dup = 0, slot = -1;
+                if (lane == 0) dup = n < (1ll << 31) ? (int)insert(c, slot) : 0;
+                if (n >= (1ll << 31)) {                           // (no table for such populations: compare against pool[0 .. i) directly)
+                    bool d = false;
+                    for (int t = lane; t < i; t += 64) d |= (uint32_t)pool[t] == c;
+                    dup = __any(d);
+                }
+                if (__builtin_amdgcn_readfirstlane(dup)) continue;      // `while j in selected: j = randbelow(n)`
                 if (lane == 0) pool[i] = (int)c;
                 if (++i == k) { consumed = l + 1; break; }
             }
             __builtin_amdgcn_wave_barrier();
             idx += consumed;
+        }
+        if (looped) {                                             // the selection, from pool[] into the lanes' register slots
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; q++) sel[q] = q * 64 + lane < k ? (long long)(uint32_t)pool[q * 64 + lane] : -1;
         }
     } else {
         for (int i = lane; i < (int)n; i += 64) pool[i] = i;
