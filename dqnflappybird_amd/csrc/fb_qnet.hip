@@ -1099,7 +1099,8 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
 // slot, chunk c + 4 in flight from global).  A slice with only 12 chunks runs its 13th on the zero page.
 constexpr int FC1_SP_KS = 4;
 struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; const uint4 *w; float *hfp; int stot, M, N;
-                 const unsigned *pver; unsigned *wver; };       // (behind the fused acting trunk, which re-split W_fc1's planes if they were stale: record it)
+                 const unsigned *pver; unsigned *wver;          // (behind the fused acting trunk, which re-split W_fc1's planes if they were stale: record it)
+                 const uint4 *w2; int m_split; };               // rows from m_split on (a multiple of the 128-row tile) take the weights w2: the target net's slices in the same launch
 
 template <int NS>
 __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
@@ -1124,9 +1125,10 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     const uint16_t *pa0 = a.ain + (size_t)r0 * 1600 + (size_t)cbase * 32 + (threadIdx.x & 3) * 8;
     const uint16_t *pa1 = a.ain + (size_t)r1 * 1600 + (size_t)cbase * 32 + (threadIdx.x & 3) * 8;
     auto ldA = [&](int c, int p, int i) { return *reinterpret_cast<const uint4 *>((i ? pa1 : pa0) + p * a.aplane + c * 32); };
+    const uint4 *wsel = a.w2 && m0 >= a.m_split ? a.w2 : a.w;
     auto pbq = [&](int q) {
         const int e = wave + 4 * q, k8 = e / NPL, pl = e - k8 * NPL;
-        return a.w + ((size_t)(cbase * 4 + k8) * 3 + P0 + pl) * a.N + n0 + lane;
+        return wsel + ((size_t)(cbase * 4 + k8) * 3 + P0 + pl) * a.N + n0 + lane;
     };
     const uint4 *pb0 = pbq(0), *pb1 = pbq(NPL == 2 ? 1 : 0);
     const size_t bstep = (size_t)12 * a.N;
@@ -3045,8 +3047,23 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                         p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr,
                         s0.states, s0.w1s, s0.params + OFF_B1, s0.params, h->wsp[which], h->FC};
             Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC,
-                       fused ? pver : nullptr, fused ? wver : nullptr};
-            const dim3 gc((rows + 4) / 5), gc4((rows + 3) / 4), gf(((rows + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
+                       fused ? pver : nullptr, fused ? wver : nullptr, nullptr, 0};
+            // behind the ring-fed trunk the groups only differ in fc1's weights: when the next group (the target net's slices) follows this
+            // one row for row and starts on a tile boundary, ONE fc1 launch takes both (two launches of 128 + 64 workgroups each left
+            // half the chip idle twice: 8.9 + 8.5 us at B = 256 against one of 192)
+            if (trunk && z1 < p.ns && rows % 128 == 0) {
+                int z2 = z1 + 1;
+                while (z2 < p.ns && p.sl.s[z2].params == p.sl.s[z1].params && p.sl.s[z2].s_off == p.sl.s[z2 - 1].s_off + p.sl.s[z2 - 1].count) z2++;
+                const Slice sn = p.sl.s[z1];
+                if (z2 == p.ns && sn.s_off == row0 + rows && sn.params != s0.params) {
+                    int rows2 = 0;
+                    for (int z = z1; z < z2; z++) rows2 += p.sl.s[z].count;
+                    af.w2 = h->wsp[sn.params == h->params[1] ? 1 : 0] + WSP_WF1; af.m_split = rows; af.M = rows + rows2;
+                    z1 = z2;
+                }
+            }
+            const int rows_f = af.M;
+            const dim3 gc((rows + 4) / 5), gc4((rows + 3) / 4), gf(((rows_f + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
                 if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 4, true>), gc4, dim3(512), 0, st, c23); }      // conv1 .. conv3
                 else if (!trunk) { FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23); }      // conv3 rides in the same launch
