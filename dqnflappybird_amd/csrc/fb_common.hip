@@ -158,7 +158,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     static const bool store_ahead = !(getenv("FB_PER_STORE_AHEAD") && atoi(getenv("FB_PER_STORE_AHEAD")) == 0);      // A/B knob
     int sampled = 0;                                 // ... and, behind it on that stream, Memory.sample of this step (it needs that tree and the memory's generator)
     if (per && store_ahead && fb_replay_per_store_ahead(replay, stream) && train)
-        sampled = fb_replay_sample_ahead(replay, batch, b->idx, b->isw, b->isw32);
+        sampled = fb_replay_sample_ahead(replay, batch, b->idx, b->isw, b->isw32, stream);
     // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
     // every env has a workgroup of its own there
     FbHeadRider hrider;

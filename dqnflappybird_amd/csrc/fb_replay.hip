@@ -723,6 +723,7 @@ struct fb_replay {
     hipEvent_t ev_fork, ev_store, ev_upd;
     bool store_ahead;                // the tree part of the next fb_replay_push has been issued already; that push joins it
     bool upd_pending;                // a batch_update runs on the side stream (fb_replay_update_priorities_ahead): whatever touches the tree next joins it
+    bool store_forked;               // the run-ahead store was ordered behind the caller's stream by an event of its own (a sample behind it needs no second one)
 };
 
 // every entry point that reads or writes the tree on a caller's stream passes here first
@@ -892,6 +893,7 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
     hipStream_t st = fb_stream(stream);
     // (behind a run-ahead batch_update the side stream is already ordered after the caller's last touch of the tree -- that update's own
     // fork -- and nothing on the caller's stream has touched the tree since: no second fork)
+    h->store_forked = !h->upd_pending;
     if (!h->upd_pending && (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess)) return 0;
     if (h->per_mode == FB_PER_FAST) hipLaunchKernelGGL(per_store_fast_kernel, dim3(1), dim3(1024), 0, h->side, h->P, h->P.n_envs);
     else hipLaunchKernelGGL(per_store_slim_kernel, dim3(1), dim3(256), 0, h->side, h->P, h->P.n_envs);     // (the shape that fits beside the acting trunk)
@@ -903,9 +905,13 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
 // Memory.sample of the step whose Memory.store has just been put on the side stream (fb_replay_per_store_ahead returned 1): the draw needs
 // the tree as that store leaves it and the memory's own generator -- nothing of the env step -- so it follows the store there and the
 // push's join covers it (ev_store is recorded again behind it).  Returns 1 when issued.
-int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32) {
+int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32, void *stream) {
     static const bool on = !(getenv("FB_PER_SAMPLE_AHEAD") && atoi(getenv("FB_PER_SAMPLE_AHEAD")) == 0);      // A/B knob
     if (!on || !h || h->P.kind != FB_REPLAY_PER || !h->store_ahead || !idx || !isw || batch < 1 || batch > MAXB) return 0;
+    // the draw WRITES the caller's idx / isw buffers: it goes behind whatever the caller's stream holds so far (readers of the previous
+    // step's indices) -- the store in front of it may have been issued without a fork of its own (behind a run-ahead batch_update)
+    // (fb_vec_step issues it right behind the store: that store's own fork, if it made one, covers both)
+    if (!h->store_forked && (hipEventRecord(h->ev_fork, fb_stream(stream)) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess)) return 0;
     hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, h->side, h->P, batch, (const double *)nullptr, (long long *)idx, isw, isw32);
     if (hipGetLastError() != hipSuccess || hipEventRecord(h->ev_store, h->side) != hipSuccess) {
         (void)hipStreamSynchronize(h->side);                 // (the store's own record stands; whatever was issued is done before anyone goes on)
