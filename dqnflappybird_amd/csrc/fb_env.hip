@@ -155,7 +155,7 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
     __shared__ unsigned long long rowm[OBS];        // columns 0..62 of every output row
     __shared__ int slow_rows[OBS];
     __shared__ int nslow;
-    __shared__ int act_mail;                        // the head rider's action for the other waves
+    __shared__ int act_mail[ENV_THREADS / 64];      // the head rider's actions: wave w's result for the workgroup's w-th env
     // everything the first env of this workgroup needs from global memory is requested BEFORE the sprite tables are
     // waited for: state, action and the old nibble words travel together with the 25 KB of tables (one round trip
     // instead of three dependent ones)
@@ -190,22 +190,26 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
         for (int i = threadIdx.x; i < (int)(sizeof(EnvLds) / 16); i += ENV_THREADS) dst[i] = src[i];
         // fb_vec_step: the acting path's head rides here -- wave 0 turns this env's fc1 partial sums into its Q values and
         // its epsilon-greedy action (head_one: head_kernel's own code) while the tables above are on their way
-        if (STEP && head.on && threadIdx.x < 64) {
-            const int a = head_one_t<2>(head.c, head.params, env, threadIdx.x);      // the game has two actions (the host checks)
-            if (threadIdx.x == 0) act_mail = a;             // handed to the other waves through LDS
+        // (up to ENV_THREADS / 64 envs per workgroup: wave w takes the w-th of them, env + w * nblk -- the host makes sure there are no more)
+        if (STEP && head.on) {
+            const int hw = threadIdx.x >> 6, he = env + hw * nblk;
+            if (he < p.n_envs) {
+                const int a = head_one_t<2>(head.c, head.params, he, threadIdx.x & 63);      // the game has two actions (the host checks)
+                if ((threadIdx.x & 63) == 0) act_mail[hw] = a;     // handed to the other waves through LDS
+            }
         }
     }
     __syncthreads();
 #if ENV_EXIT == 1
     if (STEP) return;
 #elif ENV_EXIT == 5     // ... with the head rider's action and the state loads kept alive
-    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail : act0); return; }
+    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail[0] : act0); return; }
 #elif ENV_EXIT == 6     // ... and the staged tables
-    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail : act0) + (int)L.bird_hit[st0[2] * BIRD_H] + (int)L.pal[st0[3]]; return; }
+    if (STEP) { if (threadIdx.x == 0) score[bid] = st0[0] + (head.on ? act_mail[0] : act0) + (int)L.bird_hit[st0[2] * BIRD_H] + (int)L.pal[st0[3]]; return; }
 #elif ENV_EXIT == 7     // the staged tables without the head rider
     if (STEP) { if (threadIdx.x == 0) score[bid] = (int)L.bird_hit[(bid & 1) * BIRD_H] + (int)L.pal[bid & 255]; return; }
 #endif
-    if (STEP && head.on) act0 = act_mail;
+    if (STEP && head.on) act0 = act_mail[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     for (int env = bid; env < p.n_envs; env += nblk) {
@@ -219,9 +223,9 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
         }
 
         float rew = 0.1f;
-        int term = 0, score_ret = st[5], bad = 0;
+        int term = 0, score_ret = st[5], bad = 0, act = 0;
         if (STEP) {
-            const int act = first ? act0 : (int)actions[env];
+            act = first ? act0 : head.on ? act_mail[(env - bid) / nblk] : (int)actions[env];
             bad = act > 1;                                         // ValueError('Multiple input actions!'), :99-100
             if (!bad) {
                 int flapped = 0;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
                 terminal[env] = (uint8_t)term;
                 score[env] = score_ret;
                 if (push.bits) {         // Memory append (fb_replay_push) riding in this launch: the transition's scalars
-                    push.act[env] = first ? (uint8_t)act0 : actions[env]; push.rew[env] = bad ? 0.f : rew; push.term[env] = (uint8_t)term;
+                    push.act[env] = (uint8_t)act; push.rew[env] = bad ? 0.f : rew; push.term[env] = (uint8_t)term;
                     if (env == 0) *push.steps_dev = push.steps_new;
                 }
                 if (bad) atomicAdd(p.err_count, 1ull);
@@ -679,13 +683,13 @@ extern "C" int fb_env_step(fb_env_t h, const uint8_t *actions, uint8_t *frames, 
     return fb_env_step_rider(h, actions, frames, frame_bits, reward, terminal, score, nullptr, nullptr, nullptr, stream);
 }
 
-int fb_env_can_carry_head(fb_env_t h) { return h && h->grid == h->p.n_envs; }
+int fb_env_can_carry_head(fb_env_t h) { return h && (long long)h->grid * (ENV_THREADS / 64) >= h->p.n_envs; }      // a wave per env of the workgroup
 int fb_env_num_envs(fb_env_t h) { return h ? h->p.n_envs : 0; }
 
 int fb_env_step_rider(fb_env_t h, const uint8_t *actions, uint8_t *frames, uint64_t *frame_bits, float *reward, uint8_t *terminal,
                       int32_t *score, const FbSampleRider *rider, const FbPushRider *push, const FbHeadRider *head, void *stream) {
     FB_REQUIRE(h && actions && reward && terminal && score, "fb_env_step: NULL argument");
-    FB_REQUIRE(!head || (h->grid == h->p.n_envs && head->c.A == 2), "fb_env_step: the head rider needs one workgroup per env and a 2-action net");
+    FB_REQUIRE(!head || (fb_env_can_carry_head(h) && head->c.A == 2), "fb_env_step: the head rider needs at most %d envs per workgroup and a 2-action net", ENV_THREADS / 64);
     FbSampleRider r;
     FbPushRider q;
     FbHeadRider hd;
