@@ -108,7 +108,7 @@ int fb_replay_is_prioritized(fb_replay_t h);
 int fb_replay_update_priorities_ahead(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream);      // batch_update on the side stream (see fb_replay.hip); 1 when issued
 int fb_replay_per_store_ahead(fb_replay_t h, void *stream);
 int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32, void *stream);      // Memory.sample behind that store, on the same stream; 1 when issued      // the tree part of the coming push, ahead of it on a side stream (see fb_replay.hip)
-int fb_env_can_carry_head(fb_env_t h);        // 1 when every env has its own workgroup in the step launch
+int fb_env_can_carry_head(fb_env_t h);        // 1 when an env workgroup of the step launch has a wave per env it walks (<= 4 envs per workgroup)
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                           uint8_t *actions, FbHeadRider *head, void *stream);

@@ -160,7 +160,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     if (per && store_ahead && fb_replay_per_store_ahead(replay, stream) && train)
         sampled = fb_replay_sample_ahead(replay, batch, b->idx, b->isw, b->isw32, stream);
     // the acting path's last kernel (fc2 + epsilon-greedy action, one wave per env) rides in the env launch as well when
-    // every env has a workgroup of its own there
+    // an env workgroup has a wave for each of its envs there (up to four envs per workgroup: 8192 envs)
     FbHeadRider hrider;
     static const bool head_rides = !(getenv("FB_VEC_HEAD_RIDER") && atoi(getenv("FB_VEC_HEAD_RIDER")) == 0);      // tuning knob
     const int have_h = head_rides && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2;
