@@ -10,6 +10,8 @@ algo = os.environ.get("FB_TRACE_ALGO", "dqn")                  # "per": prioriti
 env, replay, net = VecGameState(n, seed=0), VecReplay(1_000_000, n, prioritized=algo == "per"), QNet(max_batch=n)
 replay.seed(0, "numpy" if algo == "per" else "cpython")
 net.init_params(0)
+if os.environ.get("FB_TRACE_DTYPE", "f32") == "bf16":       # configs[2]'s stated dtype: bf16 acting and training
+    net.set_inference_dtype("bf16"); net.set_train_dtype("bf16")
 nib = env.track_state()
 env.observe(); replay.reset(env.frame_bits)
 one = VecStep(env, replay, net, B, algo)
