@@ -37,9 +37,9 @@ FWD_FLOP = {"conv1_pool_kernel": 2 * 400 * 32 * 256, "conv2_kernel": 2 * 25 * 64
 FWD_FLOP["conv23_t_kernel"] = FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"]      # conv2 + conv3 of one state in one launch
 FWD_FLOP["fc1_fk_kernel"] = FWD_FLOP["fc1_kernel"] + FWD_FLOP["head_kernel"]           # fc1 + the head's per-tile shares
 BWD_FLOP = {"fc1_bwd2_kernel": 2 * 2 * 1600 * 512,                # loss + head + fc1 dW + dX in one launch
-            # conv3^T + conv2^T data gradients per sample, the conv3 weight gradient beside them (+ W_fc1's Adam span: HBM)
-            "conv_bx_kernel": 2 * 25 * 576 * 64 + 2 * 25 * 512 * 64 + 2 * 25 * 576 * 64,
-            "conv_dw21_kernel": 2 * 25 * 512 * 64 + 2 * 400 * 256 * 32}      # conv2 dW + conv1 dW
+            # the whole conv backward per sample in one launch: conv3^T + conv2^T data gradients, conv3 / conv2 / conv1 weight gradients
+            # (+ W_fc1's Adam span: HBM)
+            "conv_bw_kernel": 2 * 25 * 576 * 64 + 2 * 25 * 512 * 64 + 2 * 25 * 576 * 64 + 2 * 25 * 512 * 64 + 2 * 400 * 256 * 32}
 GATHER_BYTES = 102_417          # per sampled transition
 ADAM_BYTES = 28                 # per parameter
 ENV_BYTES = 6_400 + 64          # per env-step
@@ -327,10 +327,8 @@ def main():
                 add(name + "[train 2B=64, gathered minibatch]", us, 0, "mfma", FWD_FLOP[name] * 2 * BATCH)
             elif name in FWD_FLOP:
                 add(name + "[train 2B=64]", us, 1, "mfma", FWD_FLOP[name] * 2 * BATCH)
-            elif name == "conv_bx_kernel":                    # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
-                add(name + "[conv3^T / conv2^T chain + conv3 dW + Adam of W_fc1 (HBM part priced)]", us, 1, "hbm", ADAM_BYTES * 1600 * 512)
-            elif name == "conv_dw21_kernel":
-                add(name + "[gathered minibatch]", us, 0, "mfma", BWD_FLOP[name] * BATCH)      # (full loop: the <ring> variant below)
+            elif name == "conv_bw_kernel":                    # carries W_fc1's Adam update (22.9 MB of HBM traffic) as extra workgroups
+                add(name + "[gathered minibatch: per-sample conv3^T / conv2^T chain + conv3 / conv2 / conv1 dW + Adam of W_fc1 (HBM part priced)]", us, 0, "hbm", ADAM_BYTES * 1600 * 512)      # (full loop: the <ring> variant below)
             elif name in BWD_FLOP:
                 add(name, us, 1, "mfma", BWD_FLOP[name] * BATCH)
             elif name == "adam_fused_kernel":                 # 80 K parameters + their slab sums: a dependent-load chain, not a stream
@@ -343,7 +341,7 @@ def main():
         # what the full loop launches instead of gather + conv1 + conv2/3: the conv trunk of every sampled state, fed from the 1-bit ring
         for k, nm, flop in ((1, "conv23_t_kernel<ring>[train 2B=64: conv1 + pool + conv2 + conv3 from the frame ring]",
                              (FWD_FLOP["conv1_pool_kernel"] + FWD_FLOP["conv23_t_kernel"]) * 2 * BATCH),
-                            (8, "conv_dw21_kernel<ring>", BWD_FLOP["conv_dw21_kernel"] * BATCH)):
+                            (7, "conv_bw_kernel<ring>[per-sample conv3^T / conv2^T chain + conv3 / conv2 / conv1 dW; Adam of W_fc1 rides (22.9 MB)]", BWD_FLOP["conv_bw_kernel"] * BATCH)):
             us = ev_time(lambda: L.check(lib.fb_profile_ring_kernel(replay.h, scratch.h, k, R, 0, BATCH, L.ptr(idx), L.ptr(a), L.ptr(r),
                                                                     L.ptr(t), L.ptr(loss), st()), "profile ring"), R)
             c1, c23 = FWD_FLOP["conv1_pool_kernel"], FWD_FLOP["conv23_t_kernel"]
@@ -475,7 +473,7 @@ def main():
             "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",
                        "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
                        "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
-                       "train_leg": "fb_train_steps(10) in one hipGraph: 10 x (random.sample -> ring-fed six-launch train step)" if graph_used else "eager",
+                       "train_leg": "fb_train_steps(10) in one hipGraph: 10 x (random.sample -> ring-fed five-launch train step)" if graph_used else "eager",
                        "train_only": {"grad_steps_per_sec": round(grad_steps_per_s, 1), "us_per_grad_step": round(1e6 * world / grad_steps_per_s, 2),
                                       "grad_steps_per_sec_eager": round(grad_steps_eager, 1)},
                        "env_only_steps_per_sec": round(env_only, 1),

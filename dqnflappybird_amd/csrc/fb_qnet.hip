@@ -1987,10 +1987,18 @@ struct BxArgs { const float *dh3, *h2, *p1; float *dh2, *dp1; const uint4 *w3t, 
 
 template <int NS> struct BxLds { static constexpr int NPL = NS == 3 ? 2 : 1, U4 = 2 * NPL * 200 + 16 + 2048 + 4; };      // uint4 units (+ 4: the per-wave maxima of the gradient pre-scale)
 
-template <int NS>
-__device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *smem) {
+// MODE 0: the launch's own role (dh2 / dp1 go to global memory for the weight-gradient launches that follow: batches > 64).
+// MODE 1 / 2 (conv_bw_kernel, batches <= 64: the chain is the first part of a workgroup that goes on to weight gradients of ITS sample):
+//   1  the whole chain; dp1 goes to `ldsout` (LDS of the caller, outside smem) as fp32 [100 pixels][32 channels];
+//      `hook` runs behind the first barrier that follows the planes' first writes (the caller's LDS work that must follow ITS zeroing)
+//   2  conv3^T only; dh2 goes to `ldsout` as fp32 [25 pixels][64 channels]
+// Nothing is written to global memory in modes 1 / 2, and the caller places the barrier behind the LDS result.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NS, int MODE = 0, class Hook = NoHook>
+__device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *smem, float *ldsout = nullptr, Hook hook = Hook()) {
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;
     constexpr int C2_P = 200, D2O = NPL * C2_P, ZOFF = 2 * NPL * C2_P, RED = ZOFF + 16;
+    constexpr int NCH = MODE == 2 ? 9 : 17;                                 // weight chunks this mode walks
     float *red = reinterpret_cast<float *>(smem + RED);
     float *sx = red + 8192;                                              // 8 + 8 words: per-wave maxima of dh3, then of dh2 (pow2_scale)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = lane & 31;
@@ -2017,7 +2025,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
     const float4 m2 = *reinterpret_cast<const float4 *>(a.h2 + ((size_t)b * 25 + (rowok ? j : 0)) * 64 + chA);
     const int clsB = wave & 3, halfB = wave >> 2, qy = j / 5, qx = j - qy * 5;
     const int pixB = ((clsB >> 1) + 2 * qy) * 10 + (clsB & 1) + 2 * qx, ciB = 16 * halfB + 4 * hl;   // conv2^T: channels ciB.. and ciB + 8..
-    const float *p1p = a.p1 + ((size_t)b * 100 + (rowok ? pixB : 0)) * 32 + ciB;
+    const float *p1p = a.p1 + ((size_t)b * 100 + (rowok && MODE != 2 ? pixB : 0)) * 32 + ciB;
     const float4 m1a = reinterpret_cast<const float4 *>(p1p)[0], m1b = reinterpret_cast<const float4 *>(p1p)[2];
     // The sample's gradients are tiny (1e-6 .. 1e-8 with a mean loss): the two-plane fp16 operands get an exact power-of-two pre-scale
     // from the sample's own maximum |dh3| (S3) and, further down, |dh2| (S2); 1 / S is folded back where a sum leaves the matrix
@@ -2043,6 +2051,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
         if (tid < 16) smem[ZOFF + tid] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
+    hook();
     f32x16 acc = {0}, acl = {0};
     auto park = [&](int slot) {
 #pragma unroll
@@ -2053,7 +2062,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
     };
     const int iyA = j / 5, ixA = j - iyA * 5;
 #pragma unroll
-    for (int cc = 0; cc < 17; cc++) {
+    for (int cc = 0; cc < NCH; cc++) {
         int aidx[NPL];
         if (cc < 9) {                                                    // conv3^T, tap cc: output pixel = input pixel + 1 - tap
             const int kq = wave >> 1, ky = cc / 3, oy = iyA + 1 - ky, ox = ixA + 1 - (cc - 3 * ky), pix = oy * 5 + ox;
@@ -2073,7 +2082,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
         for (int p = 0; p < NPL; p++) A[p] = smem[aidx[p]];
         const WF W = w0;
         w0 = w1; w1 = w2;
-        if (cc + 3 < 17) w2 = loadW(cc + 3);
+        if (cc + 3 < NCH) w2 = loadW(cc + 3);
         if constexpr (NS == 3) {
             acl = mfma_h(W.v[0], A[1], acl);
             acl = mfma_h(W.v[1], A[0], acl);
@@ -2090,6 +2099,10 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
                 for (int k = 1; k < 4; k++) v[e] += red[((k * 2 + ctA) * 16 + 4 * qA + e) * 64 + lane];
             }
             v[0] = m2.x > 0.f ? v[0] : 0.f; v[1] = m2.y > 0.f ? v[1] : 0.f; v[2] = m2.z > 0.f ? v[2] : 0.f; v[3] = m2.w > 0.f ? v[3] : 0.f;
+            if constexpr (MODE == 2) {                                   // the chain ends here: dh2 (true value) as fp32 in LDS
+                if (rowok) *reinterpret_cast<float4 *>(ldsout + j * 64 + chA) = make_float4(v[0] * S3.inv, v[1] * S3.inv, v[2] * S3.inv, v[3] * S3.inv);
+                return;
+            }
             if constexpr (NS == 3) {
                 // v = S3 * dh2.  Its planes get their own scale from the sample's maximum (the lanes of rows >= 25 hold sums over the
                 // zero page: 0); what goes to memory is the true value
@@ -2098,7 +2111,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
                 S2 = pow2_scale(wg_max_read<8>(sx + 8));
             }
             if (rowok) {
-                *reinterpret_cast<float4 *>(a.dh2 + ((size_t)b * 25 + j) * 64 + chA) = make_float4(v[0] * S3.inv, v[1] * S3.inv, v[2] * S3.inv, v[3] * S3.inv);
+                if constexpr (MODE == 0) *reinterpret_cast<float4 *>(a.dh2 + ((size_t)b * 25 + j) * 64 + chA) = make_float4(v[0] * S3.inv, v[1] * S3.inv, v[2] * S3.inv, v[3] * S3.inv);
                 if constexpr (NS == 3) { v[0] *= S2.s; v[1] *= S2.s; v[2] *= S2.s; v[3] *= S2.s; }
                 uint32_t h0, l0, h1, l1, m_;
                 if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
@@ -2116,7 +2129,7 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (red[((0 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane] + red[((1 * 4 + clsB) * 16 + 8 * halfB + e) * 64 + lane]) * S2.inv * S3.inv;
     if (rowok) {
-        float *o = a.dp1 + ((size_t)b * 100 + pixB) * 32 + ciB;
+        float *o = MODE == 1 ? ldsout + pixB * 32 + ciB : a.dp1 + ((size_t)b * 100 + pixB) * 32 + ciB;
         reinterpret_cast<float4 *>(o)[0] = make_float4(m1a.x > 0.f ? v[0] : 0.f, m1a.y > 0.f ? v[1] : 0.f, m1a.z > 0.f ? v[2] : 0.f, m1a.w > 0.f ? v[3] : 0.f);
         reinterpret_cast<float4 *>(o)[2] = make_float4(m1b.x > 0.f ? v[4] : 0.f, m1b.y > 0.f ? v[5] : 0.f, m1b.z > 0.f ? v[6] : 0.f, m1b.w > 0.f ? v[7] : 0.f);
     }
@@ -2460,6 +2473,243 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
     adam_span_body((int)blockIdx.x - n2 - NSP * B, n_adam, span);
 }
 
+// ==================================================================================================================================
+// ---- the conv backward of a SMALL batch (B <= 64) in ONE launch: conv_bw_kernel.
+// conv_bx_kernel -> conv_dw21_kernel is a grid-wide seam only because the weight-gradient tiles above reduce over SAMPLES inside a tile,
+// so every tile needs every sample's dh2 / dp1.  Per sample nothing crosses workgroups: dW3 of sample b needs dh3[b] and h2[b]; dW2 needs
+// dh2[b] (the first half of b's data-gradient chain) and p1[b]; dW1 needs dp1[b] (the whole chain) and b's frames.  So sample b gets FOUR
+// workgroups that share nothing and each write their own slab rows (Adam adds the B slabs in slab order, as it already does for conv1):
+//   C1 x 2   the whole chain (conv32_bx_body, dp1 kept in LDS) -> conv1's weight gradient of half the output rows (conv1_dw2_body's
+//            arithmetic; its LDS image of the sample is built while the chain's first loads are in flight)          -> slabs 2b, 2b + 1
+//   W2       conv3^T only (dh2 kept in LDS) -> the 32 tiles of dW2[tap][ci][co] = sum over the 25 output pixels, fp32 MFMA -> slab b
+//   W3       no chain at all -> the 36 tiles of dW3 likewise                                                             -> slab b
+// The chain is computed three times per sample -- on CUs that the old launches left idle (B = 32: 128 workgroups + the Adam span on
+// 256 CUs) -- which is what lets every role start at once and removes the launch boundary (~8 us in situ) between chain and tiles.
+// dh2 / dp1 never go to global memory.  W_fc1's Adam span and fb_train_steps' sampler ride as in conv_bx_kernel.
+constexpr int BW1_ROWS = 44, BW1_IMG_U4 = BW1_ROWS * DW1_IMG_W * 4 / 16;      // the image rows one half needs: 4 oy + ky, oy in [10 part, 10 part + 10)
+constexpr int BW_AUX_U4 = 1200, BW_DP1_U4 = 800;                             // aux: C1's image (1144) | W2's p1 + dh2 (800 + 400) | W3's dh3 + h2 (400 + 400)
+template <int NS> struct BwLds { static constexpr int CH = BxLds<NS>::U4, U4 = CH + BW_AUX_U4 + BW_DP1_U4; };
+static_assert(BW1_IMG_U4 <= BW_AUX_U4, "C1's image lives in the aux area");
+
+// per-sample weight-gradient tiles from LDS-resident fp32 operands: xs[IH * IW][CI], dys[25][64]; wave w takes tiles w, w + 8, ..;
+// k = output pixel, 13 steps of v_mfma_f32_32x32x2_f32 (lane half hl supplies pixel 2 t + hl; pixel 25 is padding)
+template <int LAYER>
+__device__ __forceinline__ void dw_sample_tiles(const float *xs, const float *dys, float *__restrict__ o, bool rb) {
+    using G = DwGeom<LAYER>;
+    constexpr int NT = G::CELLS * G::CIT * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31;
+    for (int tile = wave; tile < NT; tile += 8) {
+        const int cot = tile & 1, cit = G::CIT == 2 ? (tile >> 1) & 1 : 0, cell = tile / (2 * G::CIT), ky = cell / G::K, kx = cell - ky * G::K;
+        float a[13], bb[13];
+#pragma unroll
+        for (int t = 0; t < 13; t++) {
+            const int m = 2 * t + hl;
+            const int oy = hl ? (2 * t + 1) / 5 : (2 * t) / 5, ox = hl ? (2 * t + 1) % 5 : (2 * t) % 5;
+            const bool ok = t < 12 || hl == 0;
+            const int iy = oy * G::S + ky - G::P, ix = ox * G::S + kx - G::P;
+            const bool in = ok && iy >= 0 && iy < G::IH && ix >= 0 && ix < G::IW;
+            const float xv = xs[(in ? iy * G::IW + ix : 0) * G::CI + cit * 32 + i], dv = dys[(ok ? m : 0) * 64 + cot * 32 + i];
+            a[t] = in ? xv : 0.f; bb[t] = ok ? dv : 0.f;
+        }
+        f32x16 acc = {0};
+#pragma unroll
+        for (int t = 0; t < 13; t++) acc = mfma(rbf(a[t], rb), rbf(bb[t], rb), acc);
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[G::WOFF + (size_t)(cell * G::CI + cit * 32 + drow(r, lane)) * G::CO + cot * 32 + i] = acc[r];
+    }
+}
+// db[co] = sum over the 25 pixels of dys[pix][co], in pixel order
+__device__ __forceinline__ void dw_sample_bias(const float *dys, float *__restrict__ ob) {
+    if (threadIdx.x < 64) {
+        float sum = dys[threadIdx.x];
+#pragma unroll
+        for (int m = 1; m < 25; m++) sum += dys[m * 64 + threadIdx.x];
+        ob[threadIdx.x] = sum;
+    }
+}
+
+// what conv1's weight-gradient half asks of global memory, requested before the chain: the pool positions of its dY fragments and its
+// 840 image chunks (4 pixels x 4 frames each; part p needs input rows [40 p - 2, 40 p + 42) of the 80)
+struct Bw1Pre { int am[2][4]; uint4 pxa, pxb; };
+template <bool RING>
+__device__ __forceinline__ Bw1Pre bw1_request(int b, int part, const uint8_t *__restrict__ states, const uint8_t *__restrict__ amax, Dw1Ring ring) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, c = lane & 31, s0 = part * 15;
+    Bw1Pre r;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int ls = wave + 8 * u, g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int px = (ox0 >> 1) + q;
+            const bool ok = ls < 15 && px < 10;
+            r.am[u][q] = amax[((uint32_t)b * 100u + (uint32_t)(ok ? (oy >> 1) * 10 + px : 0)) * 32u + (uint32_t)c];
+        }
+    }
+    const int i0 = part ? 760 : 0, ia = i0 + tid, ib = i0 + (tid < 328 ? 512 + tid : 0);
+    if constexpr (!RING) {
+        const uint4 *sp = reinterpret_cast<const uint4 *>(states + (size_t)b * 25600);
+        r.pxa = sp[ia]; r.pxb = sp[ib];
+    } else {
+        const unsigned long long f0 = ring.fo[b * 4], f1 = ring.fo[b * 4 + 1], f2 = ring.fo[b * 4 + 2], f3 = ring.fo[b * 4 + 3];
+        auto chunk = [&](int i) {
+            const int pp = i * 4, w = pp >> 6, sh = pp & 63;
+            const uint32_t n0 = (uint32_t)(ring.bits[f0 + w] >> sh) & 0xFu, n1 = (uint32_t)(ring.bits[f1 + w] >> sh) & 0xFu,
+                           n2 = (uint32_t)(ring.bits[f2 + w] >> sh) & 0xFu, n3 = (uint32_t)(ring.bits[f3 + w] >> sh) & 0xFu;
+            return make_uint4(expand4(n0, n1, n2, n3, 0), expand4(n0, n1, n2, n3, 1), expand4(n0, n1, n2, n3, 2), expand4(n0, n1, n2, n3, 3));
+        };
+        r.pxa = chunk(ia); r.pxb = chunk(ib);
+    }
+    return r;
+}
+// the chunks into the (zeroed) image: local row = input row + 2 - 40 part, 16-byte column 1 + chunk column
+__device__ __forceinline__ void bw1_put(const Bw1Pre &pre, int part, uint4 *img4) {
+    const int tid = threadIdx.x, i0 = part ? 760 : 0;
+    auto put = [&](int i, const uint4 v) {
+        const int row = i / 20, col4 = i - row * 20;
+        img4[((row + 2 - 40 * part) * DW1_IMG_W + 4 + 4 * col4) / 4] = v;
+    };
+    put(i0 + tid, pre.pxa);
+    if (tid < 328) put(i0 + 512 + tid, pre.pxb);
+}
+// conv1_dw2_body<2>'s arithmetic from the fragments on: dY = dp1 (LDS, fp32 [100][32]) routed to the pool maxima, two fp16 planes behind a
+// power-of-two pre-scale from this workgroup's maximum; wave ky walks the 15 steps.  bfr: 15 x 2 x 64 + 64 + 4 uint4 (the chain's dead `red`).
+__device__ __forceinline__ void bw1_main(int blk, int part, const Bw1Pre &pre, const float *dp1s, const uint4 *img4, uint4 *bfr,
+                                         float *__restrict__ slabs, size_t slab_stride) {
+    constexpr int SW = 15, PU = 2;
+    float (*bsum)[32] = reinterpret_cast<float (*)[32]>(bfr + SW * 2 * 64);
+    float *sx = reinterpret_cast<float *>(bfr + SW * 2 * 64 + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, c = lane & 31, s0 = part * SW;
+    const uint8_t *img = reinterpret_cast<const uint8_t *>(img4);
+    float dv[PU][4];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int ls = wave + 8 * u, g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int px = (ox0 >> 1) + q;
+            const bool ok = ls < SW && px < 10;
+            dv[u][q] = dp1s[(ok ? (oy >> 1) * 10 + px : 0) * 32 + c];
+            m = fmaxf(m, ls < SW ? fabsf(dv[u][q]) : 0.f);
+        }
+    }
+    wg_max_write(m, sx, wave, lane);
+    __syncthreads();
+    const Pow2 S1 = pow2_scale(wg_max_read<8>(sx));
+    float bs = 0.f;
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int ls = wave + 8 * u, g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool ok = ls < SW && (ox0 >> 1) + q < 10;
+            const int pos = (oy & 1) * 2;
+            v[2 * q] = ok && pre.am[u][q] == pos ? dv[u][q] : 0.f;
+            v[2 * q + 1] = ok && pre.am[u][q] == pos + 1 ? dv[u][q] : 0.f;
+        }
+        uint4 fh, fl;
+        split2x2(v[0] * S1.s, v[1] * S1.s, fh.x, fl.x); split2x2(v[2] * S1.s, v[3] * S1.s, fh.y, fl.y);
+        split2x2(v[4] * S1.s, v[5] * S1.s, fh.z, fl.z); split2x2(v[6] * S1.s, v[7] * S1.s, fh.w, fl.w);
+        if (ls < SW) { bfr[(ls * 2 + 0) * 64 + lane] = fh; bfr[(ls * 2 + 1) * 64 + lane] = fl; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) bs += v[q];
+    }
+    bs += __shfl_xor(bs, 32);
+    if (hl == 0) bsum[wave][c] = bs;
+    __syncthreads();
+    const int ky = wave, kx = c >> 2, ci = c & 3;
+    const uint8_t *tapk = img + ((ky - 40 * part) * DW1_IMG_W + kx + 2) * 4 + ci;
+    struct Ops { uint32_t x[8]; uint4 bh, bl; };
+    auto fetch = [&](int ls) {
+        const int g = 2 * (s0 + ls) + hl, oy = g / 3, ox0 = (g - 3 * oy) * 8;
+        const uint8_t *tap = tapk + ((4 * oy) * DW1_IMG_W + 4 * ox0) * 4;
+        Ops o;
+#pragma unroll
+        for (int jq = 0; jq < 8; jq++) o.x[jq] = tap[16 * jq];
+        o.bh = bfr[(ls * 2 + 0) * 64 + lane]; o.bl = bfr[(ls * 2 + 1) * 64 + lane];
+        return o;
+    };
+    f32x16 acc = {0}, acl = {0};
+    Ops cur = fetch(0);
+#pragma unroll
+    for (int ls = 0; ls < SW; ls++) {
+        Ops nxt = cur;
+        if (ls + 1 < SW) nxt = fetch(ls + 1);
+        uint4 A;
+        {
+            const f32x2 p0 = {(float)cur.x[0], (float)cur.x[1]}, p1 = {(float)cur.x[2], (float)cur.x[3]};      // u8 -> fp16 is exact
+            const f32x2 p2 = {(float)cur.x[4], (float)cur.x[5]}, p3 = {(float)cur.x[6], (float)cur.x[7]};
+            A.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, f16x2)); A.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, f16x2));
+            A.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, f16x2)); A.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, f16x2));
+        }
+        acc = mfma_h(A, cur.bh, acc);
+        acl = mfma_h(A, cur.bl, acl);
+        cur = nxt;
+    }
+    float *o = slabs + (size_t)blk * slab_stride;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[OFF_W1 + (ky * 32 + drow(r, lane)) * 32 + c] = fmaf(acl[r], F16_LO_UNSCALE, acc[r]) * S1.inv;
+    if (wave == 0 && hl == 0) {
+        float sum = bsum[0][c];
+#pragma unroll
+        for (int w = 1; w < 8; w++) sum += bsum[w][c];
+        o[OFF_B1 + c] = sum;
+    }
+}
+
+template <int NS, bool RING>
+__global__ __launch_bounds__(512) void conv_bw_kernel(BxArgs bx, int B, float *__restrict__ slabs, size_t slab_stride, float *__restrict__ slabs1,
+                                                      size_t stride1, const uint8_t *__restrict__ states, const uint8_t *__restrict__ amax, Dw1Ring ring,
+                                                      int n_adam, AdamSpan span, FbSampleRider rider, int rb) {
+    __shared__ uint4 pool[BwLds<NS>::U4];
+    static_assert(BwLds<NS>::U4 * 16 >= FB_SAMPLE_LDS_WORDS * 4, "the sampler rider borrows the pool");
+    uint4 *aux = pool + BwLds<NS>::CH;
+    float *dp1s = reinterpret_cast<float *>(aux + BW_AUX_U4);
+    const int rid = rider.k ? 1 : 0, bid = (int)blockIdx.x - rid, tid = threadIdx.x;
+    if (bid < 0) {
+        uint32_t *sw = reinterpret_cast<uint32_t *>(pool);
+        if (tid < 64) sample_cpython_body(rider.ctx, rider.k, rider.setsize, rider.out, sw, reinterpret_cast<int *>(sw + 624));
+        return;
+    }
+    if (bid < 2 * B) {                                                       // C1: chain -> half of conv1's weight gradient
+        const int b = bid >> 1, part = bid & 1;
+        const Bw1Pre pre = bw1_request<RING>(b, part, states, amax, ring);
+        for (int i = tid; i < BW1_IMG_U4; i += 512) aux[i] = make_uint4(0u, 0u, 0u, 0u);
+        conv32_bx_body<NS, 1>(bx, b, pool, dp1s, [&]() { bw1_put(pre, part, aux); });
+        __syncthreads();                                                     // dp1 complete; the chain's reduction area is free
+        bw1_main(bid, part, pre, dp1s, aux, pool + (BwLds<NS>::CH - 2048 - 4), slabs1, stride1);
+        return;
+    }
+    if (bid < 3 * B) {                                                       // W2: conv3^T -> dW2, db2
+        const int b = bid - 2 * B;
+        float *p1s = reinterpret_cast<float *>(aux), *dys = p1s + 3200;
+        const float4 *src = reinterpret_cast<const float4 *>(bx.p1 + (size_t)b * 3200);
+        const float4 xa = src[tid], xb = src[tid < 288 ? 512 + tid : 0];
+        reinterpret_cast<float4 *>(p1s)[tid] = xa;
+        if (tid < 288) reinterpret_cast<float4 *>(p1s)[512 + tid] = xb;
+        conv32_bx_body<NS, 2>(bx, b, pool, dys);
+        __syncthreads();
+        float *o = slabs + (size_t)b * slab_stride;
+        dw_sample_tiles<2>(p1s, dys, o, rb);
+        dw_sample_bias(dys, o + OFF_B2);
+        return;
+    }
+    if (bid < 4 * B) {                                                       // W3: dW3, db3 (dh3 and h2 only)
+        const int b = bid - 3 * B;
+        float *dys = reinterpret_cast<float *>(aux), *xs = dys + 1600;
+        const int q = tid < 400 ? tid : 0;
+        const float4 d = reinterpret_cast<const float4 *>(bx.dh3 + (size_t)b * 1600)[q], x = reinterpret_cast<const float4 *>(bx.h2 + (size_t)b * 1600)[q];
+        if (tid < 400) { reinterpret_cast<float4 *>(dys)[tid] = d; reinterpret_cast<float4 *>(xs)[tid] = x; }
+        __syncthreads();
+        float *o = slabs + (size_t)b * slab_stride;
+        dw_sample_tiles<3>(xs, dys, o, rb);
+        dw_sample_bias(dys, o + OFF_B3);
+        return;
+    }
+    adam_span_body(bid - 4 * B, n_adam, span);
+}
+
 // ---- conv3 / conv2 weight gradients of a LARGE batch (B a multiple of 16): one workgroup per group of 16 samples and 32 x 32 tile of
 // (input channel, output channel) [conv2: and per parity class of input pixels], on the fp16 matrix instruction with the SAMPLES as the
 // reduction dimension of one MFMA: dW[tap][ci][co] = sum over pixels of ( sum over the 16 samples of x[b][pixel + tap][ci] * dY[b][pixel][co] ),
@@ -2634,17 +2884,34 @@ __global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, int fo
     slabs[s * slab_stride + idx] = v;
 }
 
+// float4 `q4` of the conv gradient = the sum of its z slabs IN SLAB ORDER (((0 + s0) + s1) + ..): the one definition both consumers use
+// (adam_fused_kernel of the fused step, slab_reduce_kernel of the gradient-exporting one), so the two forms stay bit-identical.
+// Sixteen loads in flight at a time from clamped addresses, masked by selects (per-sample slabs: z = B = 32 is two rounds, not 32
+// dependent ones).
+__device__ __forceinline__ float4 slab_sum4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < z; s0 += 16) {
+        float4 t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = *reinterpret_cast<const float4 *>(slabs + (size_t)(s0 + q < z ? s0 + q : 0) * slab_stride + q4 * 4);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const bool ok = s0 + q < z;
+            g.x += ok ? t[q].x : 0.f; g.y += ok ? t[q].y : 0.f; g.z += ok ? t[q].z : 0.f; g.w += ok ? t[q].w : 0.f;
+        }
+    }
+    return g;
+}
+
 // sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
                                    float *__restrict__ grad) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q4 = blockIdx.x * blockDim.x + threadIdx.x, idx = q4 * 4;
     if (idx >= CONV_PARAMS) return;
     const int z = idx < OFF_W2 ? z1 : (idx < OFF_W3 ? z2 : z3);
-    float s = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < z; q++) s += slabs[q * slab_stride + idx];
-    grad[idx] = s;
+    reinterpret_cast<float4 *>(grad)[q4] = slab_sum4(slabs, slab_stride, q4, z);
 }
+static_assert(OFF_W2 % 4 == 0 && OFF_W3 % 4 == 0 && CONV_PARAMS % 4 == 0, "slab regions are float4 aligned");
 
 // TF ApplyAdam, fp32, float4 wide: THE Adam launch -- of the fused step (single GPU: the conv gradients are still spread over the
 // reduction slabs and are summed here, in slab order; W_fc1 has been updated by the AdamSpan riding in the conv3 backward launch and
@@ -2681,14 +2948,8 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     auto update = [&](long long q, int z) {          // float4 q of the flat vector; z > 0: its gradient is the sum of z slabs, in slab order
         float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
         float4 Gv;
-        if (z > 0) {
-            Gv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int s = 0; s < z; s++) {
-                const float4 t = *reinterpret_cast<const float4 *>(a.slabs + s * a.slab_stride + q * 4);
-                Gv.x += t.x; Gv.y += t.y; Gv.z += t.z; Gv.w += t.w;
-            }
-        } else Gv = reinterpret_cast<const float4 *>(a.g)[q];
+        if (z > 0) Gv = slab_sum4(a.slabs, a.slab_stride, q, z);
+        else Gv = reinterpret_cast<const float4 *>(a.g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
         reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
         return P;
@@ -3178,6 +3439,28 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             // (conv_dwg_kernel) instead of as 38 + 34 tiles per slab inside the two launches below; one slab per group
             const bool dwg = big && B % 16 == 0;
             const int zt3 = dwg ? 0 : z3, zt2 = zt3;
+            // small batches: the whole conv backward per sample in ONE launch (conv_bw_kernel); one conv2 / conv3 slab per sample
+            static const bool bw_on = !(getenv("FB_BW_MERGED") && atoi(getenv("FB_BW_MERGED")) == 0);      // A/B knob: 0 = the two-launch form
+            const bool bw = bw_on && fk && B <= h->zmax;
+            if (bw) {
+                z3 = B;
+                FB_K(K_CONV3_BWD) {
+                    const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
+                    float *s1 = fold1 ? h->slabs1 : h->slabs;
+                    const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
+                    const dim3 g(4 * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0));
+                    const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
+                    const int n_ad = n_adam5 + n_adam5b;
+                    if (h->nsplit_train == 3) {
+                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<3, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                        else hipLaunchKernelGGL((conv_bw_kernel<3, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                    } else {
+                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<1, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                        else hipLaunchKernelGGL((conv_bw_kernel<1, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                    }
+                }
+                if (fold1) FB_K(K_CONV2_BWD) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
+            } else {
             FB_K(K_CONV3_BWD) {
                 const dim3 g(B + 38 * zt3 + n_adam5 + (srider.k ? 1 : 0));
                 if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_bx_kernel<3>, g, dim3(512), 0, st, bx, B, zt3, h->slabs, ss, n_adam5, span, srider, rbt);
@@ -3199,10 +3482,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B + n_adam5b), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
             }
+            }
         }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         const int z2 = z3;
-        if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
+        if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS / 4 + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         if (p.apply_adam) FB_K(K_ADAM)
         {
             FbGatherRider gr;
@@ -3449,9 +3733,10 @@ extern "C" int fb_qnet_profile_kernel(fb_qnet_t h, int kernel, int reps, int alg
 
 extern "C" const char *fb_qnet_kernel_name(int kernel) {
     // the launches of the SMALL-batch plans (what bench.py profiles at B = 32); ids that are no launch of their own there time as ~0:
-    // conv3 rides in conv23_t_kernel, head / loss in fc1_fk_kernel / fc1_bwd2_kernel, conv1's dW in conv_dw21_kernel
+    // conv3 rides in conv23_t_kernel, head / loss in fc1_fk_kernel / fc1_bwd2_kernel, every conv weight gradient in conv_bw_kernel
+    // (batches of 65 .. 255 and FB_BW_MERGED=0 run conv_bx_kernel + conv_dw21_kernel under the same two ids)
     static const char *names[K_COUNT] = {"conv1_pool_kernel", "conv23_t_kernel", "(conv3: in conv23_t)", "fc1_fk_kernel", "head_kernel",
-                                         "(loss: in fc1_bwd2)", "fc1_bwd2_kernel", "conv_bx_kernel", "conv_dw21_kernel",
-                                         "(conv1 dW: in conv_dw21)", "slab_reduce_kernel", "adam_fused_kernel"};
+                                         "(loss: in fc1_bwd2)", "fc1_bwd2_kernel", "conv_bw_kernel", "(conv2 / conv1 dW: in conv_bw)",
+                                         "(conv1 dW: in conv_bw)", "slab_reduce_kernel", "adam_fused_kernel"};
     return kernel >= 0 && kernel < K_COUNT ? names[kernel] : "";
 }

@@ -49,6 +49,11 @@ def allreduce_gradients(flat_grad, mean_loss):
     return flat_grad
 
 
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def broadcast_params(flat_params, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat_params, src=src)

@@ -53,6 +53,15 @@ class HipVecBackend:
         import torch
         return torch.zeros(n, dtype=torch.float32, device="cuda")
 
+    def to_device(self, x):
+        import numpy as np
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    def synchronize(self):
+        import torch
+        torch.cuda.synchronize()
+
     def train_from_replay(self, replay, net, algo, idx, isw, gamma, flat_grad, want_abs_err):
         """minibatch assembly + train step from the sampled indices on, without gathered copies -> (loss, abs_err or None)"""
         from .vec import train_from_replay
@@ -175,33 +184,67 @@ class VecBrain:
         self.dtype = dtype
 
     # ------------------------------------------------------------------ checkpoint / resume of the WHOLE loop
+    @staticmethod
+    def _npz(path):
+        return path if str(path).endswith(".npz") else str(path) + ".npz"
+
+    def _local_path(self, path):
+        """where this rank's LOCAL state goes: `<path>.rank<r>.npz` (envs, frame stacks, replay shard and stats differ per rank)"""
+        base = str(path)[:-4] if str(path).endswith(".npz") else str(path)
+        return f"{base}.rank{self.rank}.npz"
+
     def save(self, path):
         """Everything the device-resident loop needs to continue bit for bit: both nets + Adam slots (what the reference saves,
         BrainDQN.py:227-233), the three scalars, AND what it forgets (:176-192): the replay memory (frame ring, a / r / t, sampler
-        generator, SumTree), onlineTimeStep, every env's state and the agents' frame stacks."""
+        generator, SumTree), onlineTimeStep, every env's state and the agents' frame stacks.
+
+        world = 1: one file, `path`.  world > 1: the REPLICATED part (nets, Adam, scalars -- bit-identical on every rank) is written by
+        rank 0 alone to `path`; every rank writes its own envs / frame stacks / replay shard / stats to `<path>.rank<r>.npz`.  (All ranks
+        writing `path` -- round 3 -- overwrote each other's rank-local state.)  A barrier closes the call: when it returns on any rank,
+        every file of the checkpoint is complete."""
         import numpy as np
-        m, v, pows = self.net.adam_state()
-        host = lambda t: t.cpu().numpy()
-        np.savez(path, online=host(self.net.store_params(0)), target=host(self.net.store_params(1)), adam_m=host(m), adam_v=host(v),
-                 beta_pows=np.asarray(pows, np.float32), env_state=self.env.get_state(), nib=host(self.nib), stats=host(self.stats),
-                 replay=self.replay.state_blob(), scalars=np.array([self.timeStep, self.onlineTimeStep], np.int64),
-                 epsilon=np.array([self.epsilon], np.float64))
+        host = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+        local = dict(env_state=self.env.get_state(), stats=host(self.stats), replay=self.replay.state_blob())
+        if self.nib is not None:
+            local["nib"] = host(self.nib)
+        shared = None
+        if self.rank == 0:
+            m, v, pows = self.net.adam_state()
+            shared = dict(online=host(self.net.store_params(0)), target=host(self.net.store_params(1)), adam_m=host(m), adam_v=host(v),
+                          beta_pows=np.asarray(pows, np.float32), scalars=np.array([self.timeStep, self.onlineTimeStep, self.world, self.seed], np.int64),
+                          epsilon=np.array([self.epsilon], np.float64))
+        if self.world == 1:
+            np.savez(self._npz(path), **shared, **local)
+            return
+        np.savez(self._local_path(path), **local)
+        if self.rank == 0:
+            np.savez(self._npz(path), **shared)
+        fdist.barrier()
 
     def load(self, path):
+        """the inverse of save(); at world > 1 every rank reads the replicated part from `path` and its own `<path>.rank<r>.npz`
+        (the world size must be the one the checkpoint was written with: the shards are rank-local)."""
         import numpy as np
-        import torch
-        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
-        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        z = np.load(self._npz(path))
+        saved_world = int(z["scalars"][2]) if len(z["scalars"]) > 2 else 1
+        if saved_world != self.world:
+            raise ValueError(f"checkpoint {path} was written by {saved_world} rank(s), this job has {self.world}")
+        zl = np.load(self._local_path(path)) if self.world > 1 else z
+        dev = self.be.to_device if hasattr(self.be, "to_device") else np.ascontiguousarray
         self.net.load_params(z["online"], 0)
         self.net.load_params(z["target"], 1)
         self.net.set_adam_state(dev(z["adam_m"]), dev(z["adam_v"]), z["beta_pows"])
-        self.env.set_state(z["env_state"])
-        self.nib.copy_(dev(z["nib"]))
-        self.stats.copy_(dev(z["stats"]))
-        self.replay.load_state_blob(z["replay"])
+        self.env.set_state(zl["env_state"])
+        if self.nib is not None:
+            self.nib.copy_(dev(zl["nib"]))
+        self.stats[...] = dev(zl["stats"])
+        self.replay.load_state_blob(zl["replay"])
         self.timeStep, self.onlineTimeStep = int(z["scalars"][0]), int(z["scalars"][1])
+        if len(z["scalars"]) > 3:
+            self.seed = int(z["scalars"][3])                     # the key of the acting (epsilon-greedy) stream: (seed + rank, timeStep)
         self.epsilon = float(z["epsilon"][0])
-        torch.cuda.synchronize()
+        if hasattr(self.be, "synchronize"):
+            self.be.synchronize()
 
     def run(self, steps, log_every=100):
         for i in range(steps):

@@ -162,6 +162,17 @@ class CpuVecEnv:
         self.frame_bits = np.stack([g.frame80() for g in self.envs])
         return self.frame_bits
 
+    def get_state(self):
+        """the envs' C structs, byte for byte (ctypes); what fb_env_get_state is to the HIP path"""
+        import ctypes as C
+        return np.stack([np.frombuffer(bytes(g.e), np.uint8) for g in self.envs])
+
+    def set_state(self, state):
+        import ctypes as C
+        for g, row in zip(self.envs, np.asarray(state, np.uint8)):
+            C.memmove(C.byref(g.e), row.tobytes(), C.sizeof(g.e))
+        self.observe()
+
     def step(self, actions):
         out = [g.step(int(a)) for g, a in zip(self.envs, actions)]
         self.frame_bits = np.stack([g.frame80() for g in self.envs])
@@ -197,6 +208,27 @@ class CpuVecReplay:
 
     def sample(self, batch):
         return self.rng.sample(len(self.mem), batch)
+
+    def state_blob(self):
+        """the whole memory as one uint8 array: frame stacks, transitions, the sampler's generator (fb_replay_save_state's counterpart)"""
+        import ctypes as C
+        mem = np.zeros((len(self.mem), 2 * 25600 + 8), np.uint8)
+        for i, (s0, a, r, s1, t) in enumerate(self.mem):
+            mem[i, :25600], mem[i, 25600:51200] = s0.ravel(), s1.ravel()
+            mem[i, 51200] = a; mem[i, 51201] = t; mem[i, 51204:51208] = np.frombuffer(np.float32(r).tobytes(), np.uint8)
+        head = np.frombuffer(np.int64(len(self.mem)).tobytes(), np.uint8)
+        return np.concatenate([head, np.frombuffer(bytes(self.rng.s), np.uint8), np.stack(self.states).ravel(), mem.ravel()])
+
+    def load_state_blob(self, blob):
+        import ctypes as C
+        blob = np.asarray(blob, np.uint8)
+        n = int(np.frombuffer(blob[:8].tobytes(), np.int64)[0]); o_ = 8
+        sz = C.sizeof(self.rng.s)
+        C.memmove(C.byref(self.rng.s), blob[o_:o_ + sz].tobytes(), sz); o_ += sz
+        self.states = [x.copy() for x in blob[o_:o_ + self.n * 25600].reshape(self.n, 80, 80, 4)]; o_ += self.n * 25600
+        mem = blob[o_:].reshape(n, 2 * 25600 + 8)
+        self.mem = [(m[:25600].reshape(80, 80, 4).copy(), int(m[51200]), float(np.frombuffer(m[51204:51208].tobytes(), np.float32)[0]),
+                     m[25600:51200].reshape(80, 80, 4).copy(), int(m[51201])) for m in mem]
 
     def gather(self, idx):
         trs = [self.mem[int(i)] for i in idx]

@@ -141,6 +141,56 @@ def test_vecbrain_rank_logic_two_processes(tmp_path, algo):
     assert np.array_equal(brains[0].net.p[1], t[0])
 
 
+def _save_load_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from dqnflappybird_amd import dist as fdist
+    from dqnflappybird_amd.vecbrain import VecBrain
+    from tests.cpu_backend import CpuVecBackend
+    r, _, w = fdist.init("gloo")
+    ck = os.path.join(out_dir, "ck")
+
+    def run(vb, n):
+        tr = []
+        for _ in range(n):
+            vb.step()
+            tr.append(np.concatenate([vb.one_step.actions, vb.one_step.idx if vb.one_step.idx is not None else []]))
+        return np.concatenate(tr)
+
+    a = VecBrain(algo="nature", rank=r, world=w, backend=CpuVecBackend(), **VB)
+    run(a, 6)                                              # observe 3 steps, train 3
+    a.save(ck)                                             # (returns behind a barrier: every file is complete on every rank)
+    assert os.path.exists(ck + ".npz") and os.path.exists(f"{ck}.rank0.npz") and os.path.exists(f"{ck}.rank1.npz")
+    want = run(a, 4)
+    b = VecBrain(algo="nature", rank=r, world=w, backend=CpuVecBackend(), **dict(VB, seed=VB["seed"] + 50))      # other games, weights, generator
+    b.load(ck)
+    got = run(b, 4)
+    same = (np.array_equal(want, got) and np.array_equal(a.net.p[0], b.net.p[0]) and np.array_equal(a.net.p[1], b.net.p[1])
+            and np.array_equal(a.net.opt.m, b.net.opt.m) and np.array_equal(a.net.opt.v, b.net.opt.v)
+            and (a.timeStep, a.onlineTimeStep, a.epsilon) == (b.timeStep, b.onlineTimeStep, b.epsilon)
+            and np.array_equal(a.env.get_state(), b.env.get_state()))
+    np.save(os.path.join(out_dir, f"sl{rank}.npy"), np.array([int(same)]))
+    np.save(os.path.join(out_dir, f"sltrace{rank}.npy"), got)
+    np.save(os.path.join(out_dir, f"slp{rank}.npy"), b.net.p[0])
+    dist.destroy_process_group()
+
+
+def test_vecbrain_save_load_two_ranks(tmp_path):
+    """VecBrain.save / load at world size 2: rank 0 alone writes the replicated nets + Adam to `path`, every
+    rank its own envs / frame stacks / replay shard to `<path>.rank<r>.npz`; a fresh VecBrain per rank (other seed) that loads the
+    checkpoint continues with the same actions, sampled indices, parameters and Adam slots as the brain that saved -- on BOTH ranks,
+    whose games and minibatches differ from each other."""
+    port = 29500 + (os.getpid() % 180)
+    mp.spawn(_save_load_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ok = [int(np.load(tmp_path / f"sl{r}.npy")[0]) for r in (0, 1)]
+    assert ok == [1, 1]
+    t0, t1 = np.load(tmp_path / "sltrace0.npy"), np.load(tmp_path / "sltrace1.npy")
+    assert not np.array_equal(t0, t1)                            # rank-local games / shards really were restored per rank
+    assert np.array_equal(np.load(tmp_path / "slp0.npy"), np.load(tmp_path / "slp1.npy"))      # replicas still identical
+    l0, l1 = np.load(tmp_path / "ck.rank0.npz"), np.load(tmp_path / "ck.rank1.npz")
+    assert not np.array_equal(l0["env_state"], l1["env_state"]) and "online" not in l0.files and "env_state" not in np.load(tmp_path / "ck.npz").files
+
+
 def test_single_process_is_a_no_op():
     from dqnflappybird_amd import dist as fdist
     g = torch.ones(10)
