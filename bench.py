@@ -281,6 +281,18 @@ def main():
                     k["frac_issued"] = round(split * ach / peak, 5)
                     k["note"] = (f"the kernel issues {split:.3g} fp16 MFMA products per fp32 MAC (frac_issued); peak = nominal dense fp16/bf16 MFMA; "
                                  "tools/mb/mb_mfma3.hip measures 1.47 PFLOP/s sustained on random operands with all CUs busy, 2.3 on zeros")
+            if name.startswith("gather_kernel"):
+                # the replay gather: the figure is the PMC one (HBM bytes the counters saw / time / 8 TB/s); the logical-byte basis of
+                # SURVEY 8(d) prices bytes the launch never moves (the ring stores frames as bits and shares them between s and s') and
+                # can exceed 1 -- kept as a footnote, never as `frac`
+                k["logical_GBps"], k["logical_frac"] = k["achieved"], k["frac"]
+                k["logical_basis"] = "SURVEY 8d: 102 417 B per sampled transition (footnote: more bytes than the launch moves)"
+                if k["traffic"]:
+                    k["achieved"] = round(k["traffic"] / us / 1e3, 3)
+                    k["frac"] = round(k["traffic"] / us / 1e3 / HBM_PEAK_GBS, 5)
+                    k["frac_basis"] = "PMC HBM bytes per launch (profiles/traffic.json) / time / 8 TB/s"
+                else:
+                    k["achieved"] = k["frac"] = None
             kernels.append(k)
 
         scratch = QNet(2, 512, "plain", max_batch=N_ENVS)   # profile on a scratch net (Adam really steps)
@@ -416,13 +428,26 @@ def main():
             if kk["traffic"]:
                 g_["pmc_GBps"] = round(kk["traffic"] / kk["us"] / 1e3, 1)
                 g_["pmc_frac"] = round(kk["traffic"] / kk["us"] / 1e3 / HBM_PEAK_GBS, 4)
-            g_["logical_GBps"] = kk["achieved"]
-            g_["logical_frac"] = kk["frac"]
-            g_["logical_basis"] = "SURVEY 8d: 102 417 B per sampled transition"
+            g_["footnote_logical_GBps"] = kk["logical_GBps"]          # (not a roofline figure: prices bytes the launch does not move)
+            g_["footnote_logical_basis"] = "SURVEY 8d: 102 417 B per sampled transition"
             if b == "B=32":
                 g_["bound"] = "latency (1 us of traffic in a dependent launch; an EMPTY launch costs 2.8-3.3 us here, tools/mb/mb_launch.hip): the fractions are reported, not claimed"
             roofline["replay_gather"][b] = g_
         roofline["grad_steps_per_sec"] = round(grad_steps_per_s, 1)      # (the train-only half of BASELINE.json's metric, where the driver's record keeps it)
+
+    # ---------------------------------------------------------------- the other single-GPU configurations (rank 0, N = 1 only)
+    # BASELINE.json configs[2] (Double-DQN, 4096 envs, B = 256, in fp32 and in its stated bf16) and configs[3] (prioritized replay, 1 M-slot
+    # SumTree in the reference's update order, 4096 envs) through the same device-resident loop (VecBrain: act -> env -> store -> sample ->
+    # train, one train step per env step), >= 100 ms timed each, median.  Reported under config.other_configs; never part of `value`.
+    other = None
+    if rank == 0 and world == 1 and not args.no_kernel_legs:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs as bc
+        other = []
+        for i in (1, 2, 3):
+            r_ = bc.gpu_row(i, 50 if i != 3 else 25, min_total=0.1)
+            other.append({"workload": r_["config"], "us_per_step": r_["us_per_step"], "env_steps_per_s": r_["env_steps_per_s"],
+                          "grad_steps_per_s": r_["grad_steps_per_s"], "dtype": "bf16" if r_["mode"] == "bf16" else "f32", "repeats": r_["repeats"]})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
@@ -478,6 +503,7 @@ def main():
                                       "grad_steps_per_sec_eager": round(grad_steps_eager, 1)},
                        "env_only_steps_per_sec": round(env_only, 1),
                        "replicas_bit_identical": replicas_identical,       # (N > 1 only: parameters compared across ranks after the timed legs)
+                       "other_configs": other,
                        "parallelism": (f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat gradient per step"
                                        + (" (fb_vec_step_dp: issued from the C side in two pieces, the W_fc1 / head part overlapped with the conv backward)"
                                           if native is not None else " (torch.distributed)")) if world > 1 else "single GPU"},

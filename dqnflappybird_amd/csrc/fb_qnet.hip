@@ -205,6 +205,21 @@ __device__ __forceinline__ float wg_max_read(const float *sx) {
     return m;
 }
 
+// ---- range guard of the two-plane form for ACTIVATIONS, which are split unscaled (a per-block scale like the gradients' would need the
+// block's maximum before the producing epilogue can store): h = fp16(x) overflows from 65520 on, and l = fp16((x - h) * 4096) already
+// from |x| >= 32768 on (half an ulp of h is 16 there, times 4096 = 65536).  The guaranteed range is therefore |x| < 32768 (FB_F16_RANGE).
+// The reference network's activations are O(1 .. 100) with its sigma = 0.01 weights and stay far inside; a net loaded from outside
+// (tf_bundle.py) need not.  TF's fp32 would carry on; this path would turn into inf / NaN -- or, worse, into a finite wrong number behind
+// the next relu.  So every site that splits an activation notes |x| >= FB_F16_RANGE, and a wave that saw one bumps the net's overflow
+// word (AdamDev::ovf): fb_qnet_overflow_count reports it, VecBrain / the Brain classes raise on it.  It is the only atomic in the
+// library and sits on the failure path only.  bf16 (NS = 1, FB_DTYPE_BF16) has fp32's exponent range: no guard, and the way out.
+constexpr float FB_F16_RANGE = 32768.f;
+__device__ __forceinline__ bool out_of_f16_range(float a, float b, float c, float d) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) >= FB_F16_RANGE; }
+// (call where every lane of the wave is active)
+__device__ __forceinline__ void note_overflow(bool bad, unsigned *ctr) {
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0 && ctr) atomicAdd(ctr, 1u);
+}
+
 // W_conv1 in that form: w1s[part][ky][kq][h][co][8] fp16, part 0 = h, part 1 = l (conv1's u8 input is exact in fp16, so conv1 needs
 // only x*wh and x*wl: two MFMAs per 16 k)
 __device__ __forceinline__ void split_w1(const float w, int idx /* flat index in W_conv1[8][8][4][32] */, uint16_t *__restrict__ w1s) {
@@ -415,7 +430,8 @@ struct C1Side { const uint8_t *st1, *st2; int per; float *p1; uint8_t *amax; };
 template <bool NIB>
 __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const uint8_t *__restrict__ zeros, uint16_t *__restrict__ p1s,
                                                                   size_t p1plane, int nsplit, uint4 *__restrict__ wsp, int FC,
-                                                                  const unsigned *__restrict__ pver, const unsigned *__restrict__ wver, C1Side side) {
+                                                                  const unsigned *__restrict__ pver, const unsigned *__restrict__ wver, C1Side side,
+                                                                  unsigned *__restrict__ ovf) {
     __shared__ uint4 wl[2 * 16 * 64];
     __shared__ uint4 lut[NIB ? 256 : 1];
     const int bid = blockIdx.x, nblk = gridDim.x;
@@ -480,6 +496,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
     if (tile >= ntiles) return;
     Raw cur[16], nxt[16];
     fetch(tile, cur);
+    bool bad = false;
     for (; tile < ntiles; tile += stride) {
         if (tile + stride < ntiles) fetch(tile + stride, nxt);
         int z;                                   // opaque 0: keeps the 48 weight fragments in LDS (re-read per tile)
@@ -523,7 +540,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
                                                              (uint32_t)__float_as_int(am4[2]) << 16 | (uint32_t)__float_as_int(am4[3]) << 24;
         }
         uint32_t hi[2], lo[2], m_, l_;
-        if (nsplit == 3) { split2x2(o4[0], o4[1], hi[0], lo[0]); split2x2(o4[2], o4[3], hi[1], lo[1]); }      // fp16 h / l planes
+        if (nsplit == 3) { split2x2(o4[0], o4[1], hi[0], lo[0]); split2x2(o4[2], o4[3], hi[1], lo[1]); bad |= out_of_f16_range(o4[0], o4[1], o4[2], o4[3]); }      // fp16 h / l planes
         else { split3x2(o4[0], o4[1], hi[0], m_, l_); split3x2(o4[2], o4[3], hi[1], m_, l_); lo[0] = lo[1] = 0u; }     // one bf16 plane
         if (Pp < npool) {
             uint16_t *o = p1s + ((size_t)s.s_off * 100 + Pp) * 32 + 4 * (j >> 2);
@@ -533,6 +550,7 @@ __global__ __launch_bounds__(64 * C1_WAVES) void conv1_sp_kernel(Slice s, const 
 #pragma unroll
         for (int q = 0; q < 16; q++) cur[q] = nxt[q];
     }
+    note_overflow(bad, ovf);
 }
 
 // conv2 + conv3 of that path in ONE kernel, five states per workgroup (125 of its 128 MFMA rows).  A 10x10x32
@@ -556,6 +574,7 @@ struct C23Args {
     // goes straight into conv2's LDS image and never sees HBM (p1s / pl1 unused)
     const uint8_t *nib; const uint16_t *w1s; const float *b1;
     const float *params; uint4 *wsp; int FC;  // ... and the riding re-split of W_fc1's planes for the fc1 launch that follows (pver != wver)
+    unsigned *ovf;                           // the net's overflow word (note_overflow)
 };
 
 #ifndef C23_NO_LDSR
@@ -620,6 +639,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
         if (NPL == 2) d[256] = r.v1;
     };
     BSt bstA = loadB(0), bstB = loadB(1);
+    bool bad = false;                        // an activation beyond the two-plane range was split (note_overflow at the end)
     if constexpr (C1) {
         // ---- conv1 + bias + relu + 2x2 max pool of the workgroup's states, into conv2's LDS image
         // W_fc1's planes for the fc1 launch that follows, if the parameters moved since they were split (decided on the device; the fc1
@@ -685,6 +705,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
                     if constexpr (NS == 3) {
                         const _Float16 hh = (_Float16)bv, ll = (_Float16)((bv - (float)hh) * F16_LO_SCALE);
                         d[0] = __builtin_bit_cast(uint16_t, hh); d[IN_P * 8] = __builtin_bit_cast(uint16_t, ll);
+                        bad |= bv >= FB_F16_RANGE;
                     } else d[0] = (uint16_t)f32_to_bf16_rn(bv);
                 }
             }
@@ -810,7 +831,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
             const float o0 = fmaxf(mine[4 * g] + bv.x, 0.f), o1 = fmaxf(mine[4 * g + 1] + bv.y, 0.f), o2 = fmaxf(mine[4 * g + 2] + bv.z, 0.f),
                         o3 = fmaxf(mine[4 * g + 3] + bv.w, 0.f);
             uint32_t h0, l0, h1, l1, m_;
-            if constexpr (NS == 3) { split2x2(o0, o1, h0, l0); split2x2(o2, o3, h1, l1); }
+            if constexpr (NS == 3) { split2x2(o0, o1, h0, l0); split2x2(o2, o3, h1, l1); bad |= out_of_f16_range(o0, o1, o2, o3); }
             else { split3x2(o0, o1, h0, m_, l0); split3x2(o2, o3, h1, m_, l1); }
             put(0, ct * 4 + g, make_uint2(h0, h1));
             if (NS == 3) put(1, ct * 4 + g, make_uint2(l0, l1));
@@ -844,6 +865,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
         if (rowok && bl < nloc)
             *reinterpret_cast<uint2 *>(a.a3s + p * a.pl3 + ((size_t)s0 * 25 + ml) * 64 + piece * 8 + 4 * hl) = v;
     });
+    if constexpr (NS == 3) note_overflow(bad && rowok && bl < nloc, a.ovf);      // (rows of absent states compute on garbage-free zeros anyway)
 }
 
 // conv2 + conv3 for SMALL batches (training, and any forward below 256 states): one workgroup per state, the same two-plane fp16
@@ -865,6 +887,7 @@ struct C23T {
     // ring as bits, conv1 + pool run here too (p1o / amax: its fp32 side outputs for the backward pass, rows of slice 0)
     FbRingSrc ring; float *p1o; uint8_t *amax; unsigned long long *ring_fo;
     uint16_t *a3s; size_t pl3;               // conv3's output as planes too ([plane][row * 25 + pixel][64]) when fc1_sp_kernel follows, or NULL
+    unsigned *ovf;                           // the net's overflow word (note_overflow)
 };
 
 // RING = true: conv1 of the state in front of conv2 + conv3, fed from the replay's 1-bit frame ring.  The workgroup locates its
@@ -904,6 +927,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
     };
     WF w0 = {}, w1 = {}, w2 = {};
     if (!W16 || wave < 8) { w0 = loadW(0); w1 = loadW(1); w2 = loadW(2); }
+    bool bad = false;                        // an activation beyond the two-plane range was split (note_overflow)
     if constexpr (!RING) {   // the state's conv2 input: 100 pixels x 32 channels fp32 -> planes; piece q (8 channels) of pixel pix lands on (q + (pix >> 2)) & 3
         float4 t[2];
 #pragma unroll
@@ -912,7 +936,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         for (int r = 0; r < 2; r++) {
             const int i = tid + 512 * r, pix = i >> 3, q8 = i & 7;
             uint32_t h0, l0, h1, l1, m_;
-            if constexpr (NS == 3) { split2x2(t[r].x, t[r].y, h0, l0); split2x2(t[r].z, t[r].w, h1, l1); }
+            if constexpr (NS == 3) { split2x2(t[r].x, t[r].y, h0, l0); split2x2(t[r].z, t[r].w, h1, l1); bad |= out_of_f16_range(t[r].x, t[r].y, t[r].z, t[r].w); }
             else { split3x2(t[r].x, t[r].y, h0, m_, l0); split3x2(t[r].z, t[r].w, h1, m_, l1); }
             if (i < 800) {
                 uint2 *d = reinterpret_cast<uint2 *>(smem + pix * 4 + (((q8 >> 1) + (pix >> 2)) & 3)) + (q8 & 1);
@@ -1014,13 +1038,14 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
                     if constexpr (NS == 3) {
                         const _Float16 hh = (_Float16)bv, ll = (_Float16)((bv - (float)hh) * F16_LO_SCALE);
                         d[0] = __builtin_bit_cast(uint16_t, hh); d[IN_P * 8] = __builtin_bit_cast(uint16_t, ll);
+                        bad |= bv >= FB_F16_RANGE;
                     } else d[0] = (uint16_t)f32_to_bf16_rn(bv);
                 }
             }
         }
     }
     __syncthreads();
-    if (W16 && wave >= 8) return;                    // (their part -- conv1's tiles 8 .. 12 -- is done; s_barrier only counts the waves that are left)
+    if (W16 && wave >= 8) { if constexpr (NS == 3) note_overflow(bad, a.ovf); return; }                    // (their part -- conv1's tiles 8 .. 12 -- is done; s_barrier only counts the waves that are left)
     if (RING && C23T_EXIT == 2) { if (smem[tid].x == 0x12345u) a.h2[0] = 1.f; return; }
     const int oy = j / 5, ox = j - oy * 5;
     const bool rowok = j < 25;
@@ -1045,7 +1070,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         if (rowok) *reinterpret_cast<float4 *>(out + (row * 25 + j) * 64 + ch) = make_float4(v[0], v[1], v[2], v[3]);
         if ((planes || a.a3s) && rowok) {
             uint32_t h0, l0, h1, l1, m_;
-            if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); }
+            if constexpr (NS == 3) { split2x2(v[0], v[1], h0, l0); split2x2(v[2], v[3], h1, l1); bad |= out_of_f16_range(v[0], v[1], v[2], v[3]); }
             else { split3x2(v[0], v[1], h0, m_, l0); split3x2(v[2], v[3], h1, m_, l1); }
             if (planes) {
                 uint2 *d = reinterpret_cast<uint2 *>(smem + C2O + j * 8 + ((ctp * 4 + q) ^ ((j >> 1) & 7))) + hl;
@@ -1089,6 +1114,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         if (c == 7) { finish(s.params + OFF_B2, a.h2, true); __syncthreads(); }      // conv2 done: its output becomes conv3's LDS image
     }
     finish(s.params + OFF_B3, a.h3, false);
+    if constexpr (NS == 3) note_overflow(bad, a.ovf);
 }
 
 // fc1 of that path: hfp[ks] = A[M x 1600] x W[1600 x N] over a quarter of K.  One workgroup = 128 rows x 64 columns x
@@ -1250,7 +1276,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs H) {
 //                     compares the two ON THE DEVICE and re-splits when they differ.  wverc: the same for the W_conv2 / W_conv3 part
 //                     alone, which is all the small-batch conv2+conv3 kernel needs (conv23_t_kernel; a train-only loop re-splits 70 K
 //                     weights per step, not 890 K)
-struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; int ticks, applies; unsigned pver[2], wver[2], wverc[2]; };
+struct AdamDev { float b1pow, b2pow, alpha, lr, b1, b2, eps, pad; int ticks, applies; unsigned pver[2], wver[2], wverc[2];
+                 unsigned ovf; };      // ovf: waves that split an activation beyond FB_F16_RANGE (note_overflow)
 
 struct LossArgs {
     int algo, B, FC, A, dueling;
@@ -2019,7 +2046,13 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
         }
         return r;
     };
-    WF w0 = loadW(0), w1 = loadW(1), w2 = loadW(2);
+    // (PF chunks ahead.  A chunk is ~100 ns of work and an L2 round trip 600 - 800: at three ahead the loop waits for the weight stream --
+    // 290 KB per chain, 1.9 us at a CU's 64 B / clock, the floor of this chain; conv_bw_kernel's roles go four ahead (five would pass 128 registers: one workgroup per CU).  Static indices
+    // of a fully unrolled loop: registers, no alloca.)
+    constexpr int PF = MODE == 0 ? 3 : 4;
+    WF wq[PF];
+#pragma unroll
+    for (int q = 0; q < PF; q++) wq[q] = loadW(q);
     // roles of the two finishing passes, and the masks they need (requested now)
     const int ctA = wave & 1, qA = wave >> 1, chA = ctA * 32 + 8 * qA + 4 * hl;                 // conv3^T: channels chA .. + 3 of pixel j
     const float4 m2 = *reinterpret_cast<const float4 *>(a.h2 + ((size_t)b * 25 + (rowok ? j : 0)) * 64 + chA);
@@ -2080,9 +2113,8 @@ __device__ __forceinline__ void conv32_bx_body(const BxArgs &a, int b, uint4 *sm
         uint4 A[NPL];
 #pragma unroll
         for (int p = 0; p < NPL; p++) A[p] = smem[aidx[p]];
-        const WF W = w0;
-        w0 = w1; w1 = w2;
-        if (cc + 3 < NCH) w2 = loadW(cc + 3);
+        const WF W = wq[cc % PF];
+        if (cc + PF < NCH) wq[cc % PF] = loadW(cc + PF);
         if constexpr (NS == 3) {
             acl = mfma_h(W.v[0], A[1], acl);
             acl = mfma_h(W.v[1], A[0], acl);
@@ -2148,8 +2180,9 @@ __device__ __forceinline__ float4 mul4(float4 v, float s) { return make_float4(v
 // GA: which operand is the gradient (dhf) -- it is multiplied by the power of two `gs` before the split (pow2_scale), the caller folds
 // 1 / gs back
 template <int NS, bool GA>
-__device__ __forceinline__ void mma_frag(FragF f, f32x16 &acc, f32x16 &acl, float gs) {
+__device__ __forceinline__ void mma_frag(FragF f, f32x16 &acc, f32x16 &acl, float gs, bool &bad) {
     if constexpr (NS == 3) {
+        if constexpr (!GA) bad |= fmaxf(fmaxf(fmaxf(fabsf(f.a0.x), fabsf(f.a0.y)), fmaxf(fabsf(f.a0.z), fabsf(f.a0.w))), fmaxf(fmaxf(fabsf(f.a1.x), fabsf(f.a1.y)), fmaxf(fabsf(f.a1.z), fabsf(f.a1.w)))) >= FB_F16_RANGE;      // a = h3, an activation split unscaled
         if constexpr (GA) { f.a0 = mul4(f.a0, gs); f.a1 = mul4(f.a1, gs); } else { f.b0 = mul4(f.b0, gs); f.b1 = mul4(f.b1, gs); }
         uint4 ah, al, bh, bl;
         split2x2(f.a0.x, f.a0.y, ah.x, al.x); split2x2(f.a0.z, f.a0.w, ah.y, al.y); split2x2(f.a1.x, f.a1.y, ah.z, al.z); split2x2(f.a1.z, f.a1.w, ah.w, al.w);
@@ -2172,11 +2205,12 @@ __device__ __forceinline__ void mma_frag(FragF f, f32x16 &acc, f32x16 &acl, floa
 template <int NS, int KX, int KW>
 __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float *__restrict__ params, const float *__restrict__ h3,
                                                           const float *__restrict__ dhf, float *__restrict__ dh3,
-                                                          float *__restrict__ grad, int B, int FC, const float *__restrict__ gmax) {
+                                                          float *__restrict__ grad, int B, int FC, const float *__restrict__ gmax, unsigned *__restrict__ ovf) {
     __shared__ float red[8 * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, r = lane & 31;
     const int tile = blockIdx.x;
     f32x16 acc = {0}, acl = {0};
+    bool bad = false;
     // pre-scale of the gradient operand: the maximum |dhf| of the whole matrix, from the loss kernel's per-workgroup maxima (FC / 16 <= 256
     // words: four per lane); requested here, consumed behind the fragment loads
     float gm = 0.f;
@@ -2200,14 +2234,14 @@ __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float 
             for (int q = 0; q < KX; q++) f[q] = ld(q);
             const Pow2 G = pow2_scale(wave_max(gm));
 #pragma unroll
-            for (int q = 0; q < KX; q++) mma_frag<NS, true>(f[q], acc, acl, G.s);
+            for (int q = 0; q < KX; q++) mma_frag<NS, true>(f[q], acc, acl, G.s, bad);
             if constexpr (NS == 3) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
             }
         } else {
             const Pow2 G = pow2_scale(wave_max(gm));
-            for (int q = 0; q < per; q++) mma_frag<NS, true>(ld(q), acc, acl, G.s);
+            for (int q = 0; q < per; q++) mma_frag<NS, true>(ld(q), acc, acl, G.s, bad);
             if constexpr (NS == 3) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
@@ -2242,13 +2276,14 @@ __global__ __launch_bounds__(512) void fc1_bwd_big_kernel(int n_dx, const float 
 #pragma unroll
         for (int q = 0; q < KW; q++) f[q] = ld(q);
 #pragma unroll
-        for (int q = 0; q < KW; q++) mma_frag<NS, false>(f[q], acc, acl, G.s);
+        for (int q = 0; q < KW; q++) mma_frag<NS, false>(f[q], acc, acl, G.s, bad);
     } else {
-        for (int q = 0; q < per; q++) mma_frag<NS, false>(ld(q), acc, acl, G.s);
+        for (int q = 0; q < per; q++) mma_frag<NS, false>(ld(q), acc, acl, G.s, bad);
     }
     if constexpr (NS == 3) {
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[q] = fmaf(acl[q], F16_LO_UNSCALE, acc[q]) * G.inv;
+        note_overflow(bad, ovf);
     }
     reduce_rows<8>(acc, red, wave, lane, 0, 32, [&](float v, int, int row32) {
         grad[OFF_WF1 + (size_t)(it * 32 + row32) * FC + nt * 32 + r] = v;
@@ -2479,26 +2514,33 @@ __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const flo
 // so every tile needs every sample's dh2 / dp1.  Per sample nothing crosses workgroups: dW3 of sample b needs dh3[b] and h2[b]; dW2 needs
 // dh2[b] (the first half of b's data-gradient chain) and p1[b]; dW1 needs dp1[b] (the whole chain) and b's frames.  So sample b gets FOUR
 // workgroups that share nothing and each write their own slab rows (Adam adds the B slabs in slab order, as it already does for conv1):
-//   C1 x 2   the whole chain (conv32_bx_body, dp1 kept in LDS) -> conv1's weight gradient of half the output rows (conv1_dw2_body's
-//            arithmetic; its LDS image of the sample is built while the chain's first loads are in flight)          -> slabs 2b, 2b + 1
-//   W2       conv3^T only (dh2 kept in LDS) -> the 32 tiles of dW2[tap][ci][co] = sum over the 25 output pixels, fp32 MFMA -> slab b
-//   W3       no chain at all -> the 36 tiles of dW3 likewise                                                             -> slab b
-// The chain is computed three times per sample -- on CUs that the old launches left idle (B = 32: 128 workgroups + the Adam span on
-// 256 CUs) -- which is what lets every role start at once and removes the launch boundary (~8 us in situ) between chain and tiles.
+//   C1 x 2        the whole chain (conv32_bx_body, dp1 kept in LDS) -> conv1's weight gradient of half the output rows (conv1_dw2_body's
+//                 arithmetic; its LDS image of the sample is built while the chain's first loads are in flight)     -> slabs 2b, 2b + 1
+//   W2 x BW_NW2   conv3^T only (dh2 kept in LDS) -> its share of the 32 tiles of dW2[tap][ci][co] = sum over the 25 output pixels,
+//                 fp32 MFMA from LDS-resident fp32 operands                                                          -> slab b
+//   W3 x BW_NW3   no chain at all -> its share of the 36 tiles of dW3 likewise                                       -> slab b
+// The chain is computed 2 + BW_NW2 times per sample -- on CUs that the old launches left idle (B = 32: 192 workgroups + the Adam span
+// on 256 CUs) -- which is what lets every role start at once and removes the launch boundary between chain and tiles.  A tile costs a
+// wave ~1.4 us (13 dependent 64-cycle MFMAs behind 26 LDS reads): with one workgroup per layer (4 - 5 tiles per wave) the tile roles,
+// not the chain, set the launch's length (13 us alone against 9.3 for the chain; profiles/r04_notes.md), hence the split.
 // dh2 / dp1 never go to global memory.  W_fc1's Adam span and fb_train_steps' sampler ride as in conv_bx_kernel.
 constexpr int BW1_ROWS = 44, BW1_IMG_U4 = BW1_ROWS * DW1_IMG_W * 4 / 16;      // the image rows one half needs: 4 oy + ky, oy in [10 part, 10 part + 10)
+constexpr int BW_NW2 = 2, BW_NW3 = 2, BW_WGS = 2 + BW_NW2 + BW_NW3;            // workgroups per sample
 constexpr int BW_AUX_U4 = 1200, BW_DP1_U4 = 800;                             // aux: C1's image (1144) | W2's p1 + dh2 (800 + 400) | W3's dh3 + h2 (400 + 400)
 template <int NS> struct BwLds { static constexpr int CH = BxLds<NS>::U4, U4 = CH + BW_AUX_U4 + BW_DP1_U4; };
 static_assert(BW1_IMG_U4 <= BW_AUX_U4, "C1's image lives in the aux area");
 
 // per-sample weight-gradient tiles from LDS-resident fp32 operands: xs[IH * IW][CI], dys[25][64]; wave w takes tiles w, w + 8, ..;
 // k = output pixel, 13 steps of v_mfma_f32_32x32x2_f32 (lane half hl supplies pixel 2 t + hl; pixel 25 is padding)
+#ifndef DWT_ABL
+#define DWT_ABL 0
+#endif
 template <int LAYER>
-__device__ __forceinline__ void dw_sample_tiles(const float *xs, const float *dys, float *__restrict__ o, bool rb) {
+__device__ __forceinline__ void dw_sample_tiles(const float *xs, const float *dys, float *__restrict__ o, bool rb, int sub, int nsub) {
     using G = DwGeom<LAYER>;
-    constexpr int NT = G::CELLS * G::CIT * 2;
+    constexpr int NT = DWT_ABL == 3 ? 8 : G::CELLS * G::CIT * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, i = lane & 31;
-    for (int tile = wave; tile < NT; tile += 8) {
+    for (int tile = wave + 8 * sub; tile < NT; tile += 8 * nsub) {          // workgroup `sub` of the `nsub` that share the sample's tiles
         const int cot = tile & 1, cit = G::CIT == 2 ? (tile >> 1) & 1 : 0, cell = tile / (2 * G::CIT), ky = cell / G::K, kx = cell - ky * G::K;
         float a[13], bb[13];
 #pragma unroll
@@ -2512,8 +2554,16 @@ __device__ __forceinline__ void dw_sample_tiles(const float *xs, const float *dy
             a[t] = in ? xv : 0.f; bb[t] = ok ? dv : 0.f;
         }
         f32x16 acc = {0};
+        if (DWT_ABL == 1) { float sm = 0.f;
+#pragma unroll
+            for (int t = 0; t < 13; t++) sm += a[t] * bb[t];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = sm; }
+        else {
 #pragma unroll
         for (int t = 0; t < 13; t++) acc = mfma(rbf(a[t], rb), rbf(bb[t], rb), acc);
+        }
+        if (DWT_ABL == 2) { if (acc[0] == 12345.f) o[0] = acc[3]; continue; }
 #pragma unroll
         for (int r = 0; r < 16; r++) o[G::WOFF + (size_t)(cell * G::CI + cit * 32 + drow(r, lane)) * G::CO + cot * 32 + i] = acc[r];
     }
@@ -2658,6 +2708,11 @@ __device__ __forceinline__ void bw1_main(int blk, int part, const Bw1Pre &pre, c
     }
 }
 
+// ablation switch (tools/abl_build.sh + tools/time_train_ring.py; 0 = the product): 1 C1 stops behind the chain, 2 W2 stops behind its
+// chain, 3 W3 returns at once, 4 no Adam span, 5 C1 returns at once, 6 every role but the Adam span returns at once, 7 / 8 / 9 only W3 / W2 / C1 (+ the span), 10 / 11 only C1's / W2's chain
+#ifndef CBW_ABL
+#define CBW_ABL 0
+#endif
 template <int NS, bool RING>
 __global__ __launch_bounds__(512) void conv_bw_kernel(BxArgs bx, int B, float *__restrict__ slabs, size_t slab_stride, float *__restrict__ slabs1,
                                                       size_t stride1, const uint8_t *__restrict__ states, const uint8_t *__restrict__ amax, Dw1Ring ring,
@@ -2673,16 +2728,23 @@ __global__ __launch_bounds__(512) void conv_bw_kernel(BxArgs bx, int B, float *_
         return;
     }
     if (bid < 2 * B) {                                                       // C1: chain -> half of conv1's weight gradient
+        if (CBW_ABL == 5 || CBW_ABL == 6 || CBW_ABL == 7 || CBW_ABL == 8 || CBW_ABL == 11) return;
         const int b = bid >> 1, part = bid & 1;
         const Bw1Pre pre = bw1_request<RING>(b, part, states, amax, ring);
         for (int i = tid; i < BW1_IMG_U4; i += 512) aux[i] = make_uint4(0u, 0u, 0u, 0u);
-        conv32_bx_body<NS, 1>(bx, b, pool, dp1s, [&]() { bw1_put(pre, part, aux); });
+        conv32_bx_body<NS, 1>(bx, b, pool, dp1s);
+        // the image's chunks hang on TWO dependent round trips (frame offsets -> bits): placed behind the chain, whose barriers have long
+        // ordered them behind the zeroing, they never hold it up (as a hook behind the chain's second barrier they did); bw1_main's own
+        // two barriers order them in front of the first tap read
+        bw1_put(pre, part, aux);
         __syncthreads();                                                     // dp1 complete; the chain's reduction area is free
+        if (CBW_ABL == 1 || CBW_ABL == 10) { if (dp1s[tid] == 12345.f) slabs1[0] = 1.f; return; }
         bw1_main(bid, part, pre, dp1s, aux, pool + (BwLds<NS>::CH - 2048 - 4), slabs1, stride1);
         return;
     }
-    if (bid < 3 * B) {                                                       // W2: conv3^T -> dW2, db2
-        const int b = bid - 2 * B;
+    if (bid < (2 + BW_NW2) * B) {                                            // W2: conv3^T -> its share of dW2 (+ db2)
+        if (CBW_ABL == 6 || CBW_ABL == 7 || CBW_ABL == 9 || CBW_ABL == 10) return;
+        const int b = (bid - 2 * B) / BW_NW2, sub = (bid - 2 * B) - b * BW_NW2;
         float *p1s = reinterpret_cast<float *>(aux), *dys = p1s + 3200;
         const float4 *src = reinterpret_cast<const float4 *>(bx.p1 + (size_t)b * 3200);
         const float4 xa = src[tid], xb = src[tid < 288 ? 512 + tid : 0];
@@ -2691,23 +2753,26 @@ __global__ __launch_bounds__(512) void conv_bw_kernel(BxArgs bx, int B, float *_
         conv32_bx_body<NS, 2>(bx, b, pool, dys);
         __syncthreads();
         float *o = slabs + (size_t)b * slab_stride;
-        dw_sample_tiles<2>(p1s, dys, o, rb);
-        dw_sample_bias(dys, o + OFF_B2);
+        if (CBW_ABL == 2 || CBW_ABL == 11) { if (dys[tid] == 12345.f) o[0] = 1.f; return; }
+        dw_sample_tiles<2>(p1s, dys, o, rb, sub, BW_NW2);
+        if (sub == BW_NW2 - 1) dw_sample_bias(dys, o + OFF_B2);                // (the workgroup with the fewest tiles)
         return;
     }
-    if (bid < 4 * B) {                                                       // W3: dW3, db3 (dh3 and h2 only)
-        const int b = bid - 3 * B;
+    if (bid < BW_WGS * B) {                                                  // W3: its share of dW3 (+ db3) from dh3 and h2 alone
+        if (CBW_ABL == 3 || CBW_ABL == 6 || CBW_ABL == 8 || CBW_ABL == 9 || CBW_ABL == 10 || CBW_ABL == 11) return;
+        const int b = (bid - (2 + BW_NW2) * B) / BW_NW3, sub = (bid - (2 + BW_NW2) * B) - b * BW_NW3;
         float *dys = reinterpret_cast<float *>(aux), *xs = dys + 1600;
         const int q = tid < 400 ? tid : 0;
         const float4 d = reinterpret_cast<const float4 *>(bx.dh3 + (size_t)b * 1600)[q], x = reinterpret_cast<const float4 *>(bx.h2 + (size_t)b * 1600)[q];
         if (tid < 400) { reinterpret_cast<float4 *>(dys)[tid] = d; reinterpret_cast<float4 *>(xs)[tid] = x; }
         __syncthreads();
         float *o = slabs + (size_t)b * slab_stride;
-        dw_sample_tiles<3>(xs, dys, o, rb);
-        dw_sample_bias(dys, o + OFF_B3);
+        dw_sample_tiles<3>(xs, dys, o, rb, sub, BW_NW3);
+        if (sub == BW_NW3 - 1) dw_sample_bias(dys, o + OFF_B3);
         return;
     }
-    adam_span_body(bid - 4 * B, n_adam, span);
+    if (CBW_ABL == 4) return;
+    adam_span_body(bid - BW_WGS * B, n_adam, span);
 }
 
 // ---- conv3 / conv2 weight gradients of a LARGE batch (B a multiple of 16): one workgroup per group of 16 samples and 32 x 32 tile of
@@ -2726,7 +2791,7 @@ template <int NS> struct DwgLds {
 // LAYER 3: blk = (group, ci tile, co tile); LAYER 2: blk = (group, parity class, co tile)
 template <int NS, int LAYER>
 __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs,
-                                              size_t slab_stride, uint4 *pool) {
+                                              size_t slab_stride, uint4 *pool, unsigned *ovf) {
     constexpr int NPL = DwgLds<NS>::NPL, PLH = DwgLds<NS>::PLH, ZERO = 2 * NPL * PLH;      // (halves)
     uint16_t *X = reinterpret_cast<uint16_t *>(pool), *DY = X + NPL * PLH;
     float *part = reinterpret_cast<float *>(pool + 2 * NPL * PLH / 8 + 64);
@@ -2764,13 +2829,14 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
         SY = pow2_scale(wg_max_read<8>(sx));
     }
     float bs = 0.f;
+    bool bad = false;                                                          // x is an activation, split unscaled: range guard (note_overflow)
 #pragma unroll
     for (int q = 0; q < 13; q++) {
         const int w = wave + 8 * q, pos = w % 25, bp = w / 25 + 4 * hl;
         if (w < 100) {
             const int o = (pos * 32 + r) * 16 + 2 * bp;
             uint32_t h0, l0, h1, l1, m_;
-            if constexpr (NS == 3) { split2x2(xa[q], xb[q], h0, l0); split2x2(ya[q] * SY.s, yb[q] * SY.s, h1, l1); }
+            if constexpr (NS == 3) { split2x2(xa[q], xb[q], h0, l0); split2x2(ya[q] * SY.s, yb[q] * SY.s, h1, l1); bad |= fmaxf(fabsf(xa[q]), fabsf(xb[q])) >= FB_F16_RANGE; }
             else { split3x2(xa[q], xb[q], h0, m_, l0); split3x2(ya[q], yb[q], h1, m_, l1); }
             *reinterpret_cast<uint32_t *>(X + o) = h0; *reinterpret_cast<uint32_t *>(DY + o) = h1;
             if (NS == 3) { *reinterpret_cast<uint32_t *>(X + PLH + o) = l0; *reinterpret_cast<uint32_t *>(DY + PLH + o) = l1; }
@@ -2778,6 +2844,7 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
         }
     }
     part[tid] = bs;                                                            // (all items of a thread share its channel r: 512 % 64 == 0)
+    if constexpr (NS == 3) note_overflow(bad, ovf);
     __syncthreads();
     float *o = slabs + (size_t)g * slab_stride;
     if (mid == 0 && tid < 32) {                                                // bias gradient of the co tile: column sums of dY, fixed order
@@ -2855,10 +2922,10 @@ __device__ __forceinline__ void conv_dwg_body(int blk, const float *__restrict__
 
 template <int NS>
 __global__ __launch_bounds__(512) void conv_dwg_kernel(int n3, const float *__restrict__ h2, const float *__restrict__ dh3, const float *__restrict__ p1,
-                                                       const float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride) {
+                                                       const float *__restrict__ dh2, float *__restrict__ slabs, size_t slab_stride, unsigned *__restrict__ ovf) {
     __shared__ uint4 pool[DwgLds<NS>::U4];
-    if ((int)blockIdx.x < n3) conv_dwg_body<NS, 3>(blockIdx.x, h2, dh3, slabs, slab_stride, pool);
-    else conv_dwg_body<NS, 2>(blockIdx.x - n3, p1, dh2, slabs, slab_stride, pool);
+    if ((int)blockIdx.x < n3) conv_dwg_body<NS, 3>(blockIdx.x, h2, dh3, slabs, slab_stride, pool, ovf);
+    else conv_dwg_body<NS, 2>(blockIdx.x - n3, p1, dh2, slabs, slab_stride, pool, ovf);
 }
 
 // Large batches: conv1's weight gradient reduces over B x 400 output pixels; with at most zmax = 64 slabs a wave would
@@ -2886,8 +2953,8 @@ __global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, int fo
 
 // float4 `q4` of the conv gradient = the sum of its z slabs IN SLAB ORDER (((0 + s0) + s1) + ..): the one definition both consumers use
 // (adam_fused_kernel of the fused step, slab_reduce_kernel of the gradient-exporting one), so the two forms stay bit-identical.
-// Sixteen loads in flight at a time from clamped addresses, masked by selects (per-sample slabs: z = B = 32 is two rounds, not 32
-// dependent ones).
+// Sixteen loads in flight at a time from clamped addresses, masked by selects (per-sample slabs: z = B = 32 is two round trips, not 32
+// dependent ones; thirty-two in flight -- 168 registers -- took adam_fused_kernel from 7.3 to 12.0 us in situ, profiles/r04_notes.md).
 __device__ __forceinline__ float4 slab_sum4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s0 = 0; s0 < z; s0 += 16) {
@@ -2904,7 +2971,7 @@ __device__ __forceinline__ float4 slab_sum4(const float *__restrict__ slabs, siz
 }
 
 // sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
-__global__ void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, size_t slab_stride, int z1, int z2, int z3,
                                    float *__restrict__ grad) {
     const int q4 = blockIdx.x * blockDim.x + threadIdx.x, idx = q4 * 4;
     if (idx >= CONV_PARAMS) return;
@@ -3137,6 +3204,16 @@ extern "C" int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float bet
     return FB_OK;
 }
 
+extern "C" int fb_qnet_overflow_count(fb_qnet_t h, int reset, int64_t *count_host) {
+    FB_REQUIRE(h && count_host, "fb_qnet_overflow_count: NULL argument");
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    unsigned v = 0;
+    FB_CHECK_HIP(hipMemcpy(&v, &h->adam->ovf, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset && v) { const unsigned z = 0; FB_CHECK_HIP(hipMemcpy(&h->adam->ovf, &z, sizeof(z), hipMemcpyHostToDevice)); }
+    *count_host = (int64_t)v;
+    return FB_OK;
+}
+
 extern "C" int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype) {
     FB_REQUIRE(h && (dtype == FB_DTYPE_F32 || dtype == FB_DTYPE_BF16), "fb_qnet_set_inference_dtype: dtype must be FB_DTYPE_F32 or FB_DTYPE_BF16");
     h->nsplit = dtype == FB_DTYPE_BF16 ? 1 : 3;
@@ -3260,7 +3337,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     const bool trunk = p.ring != nullptr;        // ring-fed minibatch (any batch size): the whole conv trunk per state in one launch
     if (!sp || trunk) {
         job.FC = h->FC;
-        c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3;
+        c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3; c23t.ovf = &h->adam->ovf;
         for (int z = 0; z < p.ns; z++) {
             const int which = p.sl.s[z].params == h->params[1] ? 1 : 0;
             c23t.w[z] = h->wsp[which] + WSP_W2;
@@ -3301,12 +3378,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             static const bool fuse_on = !(getenv("FB_ACT_FUSED") && atoi(getenv("FB_ACT_FUSED")) == 0);      // A/B knob
             const bool fused = fuse_on && p.nib && !p.train && !trunk && z1 - z0 == 1;
             if (!trunk && !fused) FB_K(K_CONV1) {
-                if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
-                else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side);
+                if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side, &h->adam->ovf);
+                else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side, &h->adam->ovf);
             }
             C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver, only < 0 ? &h->adam->wverc[which] : nullptr,
                         p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr,
-                        s0.states, s0.w1s, s0.params + OFF_B1, s0.params, h->wsp[which], h->FC};
+                        s0.states, s0.w1s, s0.params + OFF_B1, s0.params, h->wsp[which], h->FC, &h->adam->ovf};
             Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC,
                        fused ? pver : nullptr, fused ? wver : nullptr, nullptr, 0};
             // behind the ring-fed trunk the groups only differ in fc1's weights: when the next group (the target net's slices) follows this
@@ -3400,11 +3477,11 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             const dim3 gb(ntile);
             const bool std_shape = FC == 512 && B == 256;      // the shapes this path sees (MAXTB = 256): fully unrolled instantiation
             if (h->nsplit_train == 3) {
-                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
-                else hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax, &h->adam->ovf);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<3, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax, &h->adam->ovf);
             } else {
-                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
-                else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax);
+                if (std_shape) hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 4, 2>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax, &h->adam->ovf);
+                else hipLaunchKernelGGL((fc1_bwd_big_kernel<1, 0, 0>), gb, dim3(512), 0, st, ndx, h->params[0], h->h3, h->dhf, h->dh3, G, B, FC, (const float *)h->gmax, &h->adam->ovf);
             }
         }
         // data-parallel path: from here on G[CONV_PARAMS ..) -- W_fc1, b_fc1, the head: 91 % of the bytes -- is final; the caller's side
@@ -3448,7 +3525,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                     const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
                     float *s1 = fold1 ? h->slabs1 : h->slabs;
                     const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
-                    const dim3 g(4 * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0));
+                    const dim3 g(BW_WGS * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0));
                     const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
                     const int n_ad = n_adam5 + n_adam5b;
                     if (h->nsplit_train == 3) {
@@ -3470,8 +3547,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 z3 = B / 16;                                 // (conv2's slab count follows: z2 below)
                 FB_K(K_CONV2_BWD) {
                     const int n3 = z3 * 4, n2 = z3 * 8;
-                    if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_dwg_kernel<3>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss);
-                    else hipLaunchKernelGGL(conv_dwg_kernel<1>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss);
+                    if (h->nsplit_train == 3) hipLaunchKernelGGL(conv_dwg_kernel<3>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss, &h->adam->ovf);
+                    else hipLaunchKernelGGL(conv_dwg_kernel<1>, dim3(n3 + n2), dim3(512), 0, st, n3, h->h2, h->dh3, h->p1, h->dh2, h->slabs, ss, &h->adam->ovf);
                 }
             }
             FB_K(K_CONV2_BWD) {

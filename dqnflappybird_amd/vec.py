@@ -295,6 +295,22 @@ class QNet:
     def set_hparams(self, lr=1e-6, beta1=0.9, beta2=0.999, eps=1e-8):
         L.check(L.lib().fb_qnet_set_hparams(self.h, lr, beta1, beta2, eps), "fb_qnet_set_hparams")
 
+    def overflow_count(self, reset=False):
+        """waves that split an ACTIVATION beyond the two-plane fp16 range (|x| >= 32768, include/fbdqn.h) since creation / the last
+        reset: 0 = every forward / train step so far computed in range.  Synchronous (one device word)."""
+        v = C.c_int64()
+        L.check(L.lib().fb_qnet_overflow_count(self.h, int(bool(reset)), C.byref(v)), "fb_qnet_overflow_count")
+        return v.value
+
+    def check_range(self):
+        """raise FbError if a launch of this net met an activation beyond the fp32-equivalent path's range (its results are then
+        inf / NaN / wrong where TensorFlow's fp32 would have carried on)"""
+        n = self.overflow_count()
+        if n:
+            raise L.FbError(f"{n} wave(s) of the Q-network's fp32-equivalent (two-plane fp16) kernels met an activation of magnitude >= 32768: "
+                            "those Q-values / gradients are not to be trusted.  Use set_inference_dtype('bf16') / set_train_dtype('bf16') "
+                            "(fp32's exponent range) for this net, or rescale its weights (include/fbdqn.h, fb_qnet_overflow_count).")
+
     def set_inference_dtype(self, dtype="f32"):
         """'f32' (default) or 'bf16': arithmetic of forward / act / act_nib on >= 256 states (BASELINE config 3)."""
         L.check(L.lib().fb_qnet_set_inference_dtype(self.h, {"f32": L.DTYPE_F32, "bf16": L.DTYPE_BF16}[dtype]),

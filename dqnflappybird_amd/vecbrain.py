@@ -252,5 +252,7 @@ class VecBrain:
             if log_every and (i + 1) % log_every == 0:
                 loss = self.last_loss.item() if self.last_loss is not None else float("nan")
                 ep, ssum, smax, pipes = self.stats.tolist()      # the only host sync of the loop, once per log line
+                if hasattr(self.net, "check_range"):
+                    self.net.check_range()                       # (the same sync: an activation beyond the two-plane fp16 range raises here)
                 print(f"TIMESTEP {self.timeStep} / ENVS {self.n} / EPSILON {self.epsilon:.6f} / GAME_TIMES {ep} / "
                       f"MEAN_SCORE {ssum / max(ep, 1):.3f} / MAX_SCORE {smax} / PIPES {pipes} / LOSS {loss:.6g}", flush=True)

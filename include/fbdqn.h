@@ -244,6 +244,15 @@ int fb_qnet_set_hparams(fb_qnet_t h, float lr, float beta1, float beta2, float e
 #define FB_DTYPE_F32 0
 #define FB_DTYPE_BF16 1
 int fb_qnet_set_inference_dtype(fb_qnet_t h, int dtype);
+/* Range guard of FB_DTYPE_F32.  ACTIVATIONS are split into their two fp16 planes unscaled, so the form is exact only for
+ * |x| < FB_F16_RANGE = 32768 (h overflows from 65520 on, l already from 32768 on).  TensorFlow's fp32 (BrainDQN.py:119-155) has no such
+ * limit; the reference network's activations are O(1 .. 100) and stay far inside, a net loaded from outside need not.  Every kernel that
+ * splits an activation (acting trunk, training trunk, the large-batch weight-gradient kernels) therefore counts the waves that met
+ * |x| >= FB_F16_RANGE in a device word instead of silently producing inf / NaN (or a finite wrong number behind the next relu):
+ *   fb_qnet_overflow_count -> [host] the count since creation / the last reset (synchronous; 0 = every result so far is in range).
+ * A non-zero count means: the Q-values / gradients of those launches are NOT to be trusted; switch the net to FB_DTYPE_BF16 (fp32's
+ * exponent range) or rescale its weights.  VecBrain.run and the Brain* classes raise on it at their log cadence. */
+int fb_qnet_overflow_count(fb_qnet_t h, int reset, int64_t *count_host);
 /* Arithmetic of fb_qnet_train_step (BASELINE.json configs[2]: "bf16"):
  *   FB_DTYPE_F32  (default) fp32: the fc1 GEMMs of small batches on the fp32-input matrix instruction, everything else on two-plane fp16
  *                 (as above, gradient operands pre-scaled)

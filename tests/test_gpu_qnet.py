@@ -317,8 +317,9 @@ def test_act_epsilon_greedy(torch_cuda, oracle):
     sd = torch.from_numpy(s).cuda()
     act, q = net.act(sd, epsilon=0.0, seed=1, step=0, want_q=True)
     q = q.cpu().numpy()
-    want = oracle.forward(p, cfg, s[:64])
-    np.testing.assert_allclose(q[:64], want, rtol=0, atol=Q_ATOL)
+    want = oracle.forward(p, cfg, s)                                  # ALL 2048 rows of the >= 256-state path against the oracle
+    np.testing.assert_allclose(q, want, rtol=0, atol=Q_ATOL)
+    assert net.overflow_count() == 0
     assert np.array_equal(act.cpu().numpy(), q.argmax(1))            # greedy == np.argmax
     a1 = net.act(sd, epsilon=1.0, seed=1, step=5).cpu().numpy().copy()
     a2 = net.act(sd, epsilon=1.0, seed=1, step=6).cpu().numpy().copy()
@@ -327,6 +328,67 @@ def test_act_epsilon_greedy(torch_cuda, oracle):
     a3 = net.act(sd, epsilon=0.03, seed=1, step=7).cpu().numpy()     # INITIAL_EPSILON
     frac = (a3 != q.argmax(1)).mean()
     assert 0.003 < frac < 0.04                                        # ~ eps/2 of the envs deviate
+
+
+def test_fused_acting_trunk_all_rows_against_the_oracle(torch_cuda, oracle):
+    """The acting path VecBrain runs (nibble states -> conv1 + conv2 + conv3 in one launch -> fc1 on K slices -> head) compared with
+    the oracle DIRECTLY on every one of 1027 states (a last workgroup of three), not through its bit-identity with the u8 path."""
+    torch = torch_cuda
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
+    N = 1027
+    cfg = oracle.qcfg()
+    p = trained_like_params(oracle, cfg, 6)
+    env, rep, net = VecGameState(N, seed=9), VecReplay(5000, N), QNet(max_batch=N)
+    net.load_params(p)
+    nib = env.track_state()
+    env.observe()
+    rep.reset(env.frame_bits)
+    rng = np.random.default_rng(2)
+    for _ in range(7):                                                # (distinct frames in the four stack positions)
+        acts = torch.from_numpy((rng.random(N) < 0.3).astype(np.uint8)).cuda()
+        env.frame_step(acts, want_u8=False)
+        rep.push(env.frame_bits, acts, env.reward, env.terminal)
+    _, q = net.act_nib(nib, 0.0, want_q=True)
+    want = oracle.forward(p, cfg, rep.current_state().cpu().numpy())
+    np.testing.assert_allclose(q.cpu().numpy(), want, rtol=0, atol=Q_ATOL)
+    assert net.overflow_count() == 0
+
+
+@pytest.mark.parametrize("N", [40, 1024])
+def test_activations_beyond_the_two_plane_range_are_reported_not_silently_wrong(torch_cuda, oracle, N):
+    """the path labelled f32 carries activations as two fp16 planes, unscaled -- exact for |x| < 32768 only,
+    where TensorFlow's fp32 (BrainDQN.py:119-155) has no such limit.  A net with weights x 40 (pooled conv1 outputs ~ 1e5, conv2 /
+    conv3 outputs far beyond) used to come back as inf / NaN or as finite wrong numbers.  Now: the library COUNTS the event
+    (fb_qnet_overflow_count), QNet.check_range raises, and the same net in bf16 mode (fp32's exponent range) still tracks the oracle
+    on the Q scale.  In range (weights x 1) the counter stays 0."""
+    torch = torch_cuda
+    from dqnflappybird_amd import _lib as L
+    from dqnflappybird_amd.vec import QNet
+    rng = np.random.default_rng(5)
+    cfg = oracle.qcfg()
+    p1 = trained_like_params(oracle, cfg, 3)
+    s = rand_states(rng, N)
+    sd = torch.from_numpy(s).cuda()
+    net = QNet(max_batch=max(N, 64))
+    net.load_params(p1)
+    net.forward(sd)
+    assert net.overflow_count() == 0
+    net.check_range()
+    big = (p1 * 40.0).astype(np.float32)
+    want = oracle.forward(big, cfg, s)
+    assert np.abs(want).max() > 1e6                                   # (the oracle's own activations pass 65504 from conv1 / conv2 on)
+    net.load_params(big)
+    net.forward(sd)
+    n = net.overflow_count()
+    assert n > 0
+    with pytest.raises(L.FbError, match="32768"):
+        net.check_range()
+    assert net.overflow_count(reset=True) == n and net.overflow_count() == 0
+    if N >= 256:                                                      # the way out the message names: bf16 planes have fp32's exponent range
+        net.set_inference_dtype("bf16")
+        q = net.forward(sd).cpu().numpy()
+        assert np.isfinite(q).all() and net.overflow_count() == 0
+        assert np.abs(q - want).max() < 0.03 * np.abs(want).max()     # (the bf16 bound of tests/test_gpu_configs.py, on the Q scale)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ ROWS = [
 ]
 
 
-def gpu_row(i, steps):
+def gpu_row(i, steps, min_total=0.3):
     import torch
     from dqnflappybird_amd.vecbrain import VecBrain
     name, kw, mode = ROWS[i]
@@ -44,7 +44,7 @@ def gpu_row(i, steps):
     torch.cuda.synchronize()
     times = []
     total = 0.0
-    while total < 0.3 and len(times) < 50:       # measurements of `steps` steps until >= 300 ms are timed; report the median
+    while total < min_total and len(times) < 50:       # measurements of `steps` steps until >= min_total s are timed; report the median
         t0 = time.perf_counter()
         vb.run(steps, log_every=0)
         torch.cuda.synchronize()
@@ -52,6 +52,10 @@ def gpu_row(i, steps):
         total += times[-1]
     assert torch.isfinite(vb.last_loss).all()
     dt = sorted(times)[len(times) // 2]
+    overflow = vb.net.overflow_count()
+    assert overflow == 0, f"{overflow} wave(s) met an activation beyond the two-plane fp16 range"
+    del vb
+    torch.cuda.synchronize()
     return {"config": name, "n_envs": n_envs, "algo": kw["algo"], "arch": kw.get("arch", "plain"), "batch": kw["batch"], "mode": mode or "fp32",
             "replay_slots": 1_000_000, "steps": steps, "repeats": len(times), "us_per_step": round(dt / steps * 1e6, 2),
             "env_steps_per_s": round(n_envs * steps / dt, 1), "grad_steps_per_s": round(steps / dt, 1),
