@@ -131,6 +131,8 @@ def main():
                 dist.all_reduce(grad)
             net.apply_adam(grad)
 
+    local_times = []
+
     def timed(fn, k, first=0):
         barrier()
         t0 = time.perf_counter()
@@ -138,6 +140,7 @@ def main():
             fn(first + i)
         barrier()
         dt = time.perf_counter() - t0
+        local_times.append(dt)                              # (this rank's own clock, before the MAX over ranks)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -162,6 +165,7 @@ def main():
     for i in range(args.warmup):
         full_step(i)
     dts_full = timed_repeat(full_step, args.steps, first=args.warmup)
+    dts_full_local = list(local_times)
     dt = median(dts_full)
     ms_per_step = dt / args.steps * 1e3
     env_steps_per_s = world * N_ENVS * args.steps / dt
@@ -232,6 +236,37 @@ def main():
         replicas_identical = bool(torch.equal(lo, hi))
         if not replicas_identical and rank == 0:
             print(f"[bench] REPLICAS DIVERGED: {int((lo != hi).sum())} of {lo.numel()} parameters differ between ranks", file=sys.stderr)
+
+    # ---------------------------------------------------------------- N > 1: what the step's collective costs, and which path ran
+    # (so that a scaling record explains its own efficiency: the all-reduce alone, bracketed by HIP events on the stream it is issued
+    # from -- torch.distributed's goes through RCCL's own stream and back, which the events then include -- median of 30; and every
+    # rank's own median step time, min / max over ranks)
+    dp_path, allreduce_us, rank_ms = None, None, None
+    if grad is not None:
+        dp_path = ("native_overlap" if native.overlap else "native") if native is not None else ("torch_overlap" if reduce_grad is not None else "torch")
+    if world > 1:
+        scratch_g = torch.zeros_like(grad)
+        ts = []
+        for i in range(35):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if native is not None:
+                native.all_reduce(scratch_g)
+            else:
+                dist.all_reduce(scratch_g)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 5:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        tt = torch.tensor([median(ts)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce_us = round(tt.item(), 2)
+        mine = torch.tensor([median(dts_full_local) / args.steps * 1e3], dtype=torch.float64, device="cuda")
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rank_ms = [round(lo.item(), 4), round(hi.item(), 4)]
 
     # ---------------------------------------------------------------- leg D: per-kernel HIP-event timing
     kernels = []
@@ -504,6 +539,8 @@ def main():
                        "env_only_steps_per_sec": round(env_only, 1),
                        "replicas_bit_identical": replicas_identical,       # (N > 1 only: parameters compared across ranks after the timed legs)
                        "other_configs": other,
+                       # N > 1 (or FB_BENCH_FORCE_DP=1): which data-parallel path the step took, the collective alone, per-rank step time
+                       "dp_path": dp_path, "allreduce_us": allreduce_us, "rank_ms_per_step_min_max": rank_ms,
                        "parallelism": (f"dp{world}: envs + replay sharded per rank, one RCCL all-reduce of the flat gradient per step"
                                        + (" (fb_vec_step_dp: issued from the C side in two pieces, the W_fc1 / head part overlapped with the conv backward)"
                                           if native is not None else " (torch.distributed)")) if world > 1 else "single GPU"},

@@ -87,6 +87,7 @@ SIGNATURES = {
     "fb_vec_step_dp": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _i, _d, _i, _vp],
     "fb_dist_reduce_apply": [_vp, _vp, _vp, _i, _vp],
     "fb_dist_grad_event": [_vp],
+    "fb_dist_all_reduce": [_vp, _vp, _i64, _vp],
     "fb_qnet_set_grad_event": [_vp, _vp],
     "fb_qnet_grad_split": [_vp],
     "fb_train_from_replay": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp],

@@ -159,3 +159,11 @@ extern "C" int fb_dist_reduce_apply(fb_dist_t d, fb_qnet_t net, float *flat_grad
 }
 
 extern "C" void *fb_dist_grad_event(fb_dist_t d) { return d ? (void *)d->grad_ready : nullptr; }
+
+// the collective ALONE (sum, in place, on the caller's stream): what bench.py brackets with HIP events to report how long the all-reduce
+// itself takes at this world size (config.allreduce_us), apart from the step around it
+extern "C" int fb_dist_all_reduce(fb_dist_t d, float *buf, int64_t count, void *stream) {
+    FB_REQUIRE(d && buf && count > 0, "fb_dist_all_reduce: bad argument");
+    FB_CHECK_NCCL(rccl.AllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, d->comm, fb_stream(stream)));
+    return FB_OK;
+}

@@ -1128,6 +1128,11 @@ struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; cons
                  const unsigned *pver; unsigned *wver;          // (behind the fused acting trunk, which re-split W_fc1's planes if they were stale: record it)
                  const uint4 *w2; int m_split; };               // rows from m_split on (a multiple of the 128-row tile) take the weights w2: the target net's slices in the same launch
 
+// ablation switch (tools/abl_forward.sh; 0 = the product): 1 no global loads inside the chunk loop, 2 no MFMAs, 3 no ring writes / fragment
+// reads (no LDS traffic in the loop), 4 no output stores
+#ifndef FC1_ABL
+#define FC1_ABL 0
+#endif
 template <int NS>
 __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     constexpr int NPL = NS == 3 ? 2 : 1, P0 = NS == 3 ? 0 : 2;                   // as in conv23_sp_kernel
@@ -1196,6 +1201,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     };
     f32x16 acc[2] = {{0}, {0}}, acl[2] = {{0}, {0}};       // h*h products; h*l + l*h (folded in at the end, x 1 / 4096)
     auto compute = [&](const Fr f) {
+        if (FC1_ABL == 2) { acc[0][0] += __uint_as_float(f.A[0].x ^ f.W[0][0].y ^ f.W[1][NPL - 1].z ^ f.A[NPL - 1].w); return; }
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
             if constexpr (NS == 3) {
@@ -1214,12 +1220,12 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     // half-chunk software pipeline: the fragments of the next k-step are read while the 12 MFMAs of this one run
 #define FB_STEP(cc, ST)                                                                                    \
     {                                                                                                          \
-        const Fr f1 = readF((cc) % 3, 1);                                                                      \
+        const Fr f1 = FC1_ABL == 3 ? cur : readF((cc) % 3, 1);                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         compute(cur);                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        const Fr nx = readF(((cc) + 1) % 3, 0);                                                                \
-        if ((cc) + 2 < 13) { store(((cc) + 2) % 3, ST); if ((cc) + 4 < 13) ST = load((cc) + 4); }              \
+        const Fr nx = FC1_ABL == 3 ? cur : readF(((cc) + 1) % 3, 0);                                           \
+        if ((cc) + 2 < 13) { if (FC1_ABL != 3) store(((cc) + 2) % 3, ST); if ((cc) + 4 < 13 && FC1_ABL != 1) ST = load((cc) + 4); }              \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         compute(f1);                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -1233,6 +1239,7 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
         for_rows(m0 + wave * 32, a.M, lane, [&](int r, int mr) {
+            if (FC1_ABL == 4 && acc[ct][r] != 12345.f) return;
             a.hfp[((size_t)ks * a.stot + mr) * a.N + n0 + ct * 32 + j] = NS == 3 ? fmaf(acl[ct][r], F16_LO_UNSCALE, acc[ct][r]) : acc[ct][r];
         });
 }
@@ -2951,23 +2958,35 @@ __global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, int fo
     slabs[s * slab_stride + idx] = v;
 }
 
-// float4 `q4` of the conv gradient = the sum of its z slabs IN SLAB ORDER (((0 + s0) + s1) + ..): the one definition both consumers use
-// (adam_fused_kernel of the fused step, slab_reduce_kernel of the gradient-exporting one), so the two forms stay bit-identical.
-// Sixteen loads in flight at a time from clamped addresses, masked by selects (per-sample slabs: z = B = 32 is two round trips, not 32
-// dependent ones; thirty-two in flight -- 168 registers -- took adam_fused_kernel from 7.3 to 12.0 us in situ, profiles/r04_notes.md).
-__device__ __forceinline__ float4 slab_sum4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z) {
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < z; s0 += 16) {
-        float4 t[16];
+// The conv gradient of float4 `q4` = the sum of its z <= 64 slabs in ONE canonical order that both consumers use (adam_fused_kernel of
+// the fused step, slab_reduce_kernel of the gradient-exporting one), so the two forms stay bit-identical:
+//     chunk c = (((0 + s[16 c]) + s[16 c + 1]) + ..) over its <= 16 slabs, in slab order;      G = ((C0 + C1) + C2) + C3   (absent chunks: + 0)
+// A chunk is sixteen loads in flight at once from clamped addresses, masked by selects; the chunks are independent, so the Adam kernel
+// gives each to its own lane (per-sample slabs: z = 32 / 64 is one round trip there, not two / four; thirty-two loads in flight on
+// ONE lane -- 168 registers -- took that kernel from 7.3 to 12.0 us in situ, profiles/r04_notes.md).
+constexpr int SLAB_CHUNK = 16, SLAB_NCH = 4;
+__device__ __forceinline__ float4 slab_chunk4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z, int c) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), t[SLAB_CHUNK];
+    const int s0 = c * SLAB_CHUNK;
 #pragma unroll
-        for (int q = 0; q < 16; q++) t[q] = *reinterpret_cast<const float4 *>(slabs + (size_t)(s0 + q < z ? s0 + q : 0) * slab_stride + q4 * 4);
+    for (int q = 0; q < SLAB_CHUNK; q++) t[q] = *reinterpret_cast<const float4 *>(slabs + (size_t)(s0 + q < z ? s0 + q : 0) * slab_stride + q4 * 4);
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const bool ok = s0 + q < z;
-            g.x += ok ? t[q].x : 0.f; g.y += ok ? t[q].y : 0.f; g.z += ok ? t[q].z : 0.f; g.w += ok ? t[q].w : 0.f;
-        }
+    for (int q = 0; q < SLAB_CHUNK; q++) {
+        const bool ok = s0 + q < z;
+        g.x += ok ? t[q].x : 0.f; g.y += ok ? t[q].y : 0.f; g.z += ok ? t[q].z : 0.f; g.w += ok ? t[q].w : 0.f;
     }
     return g;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 slab_combine4(float4 c0, float4 c1, float4 c2, float4 c3) { return add4(add4(add4(c0, c1), c2), c3); }
+// (one thread, chunk after chunk: the gradient-exporting path's slab_reduce_kernel)
+__device__ __forceinline__ float4 slab_sum4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 c0 = slab_chunk4(slabs, slab_stride, q4, z, 0);
+    const float4 c1 = z > SLAB_CHUNK ? slab_chunk4(slabs, slab_stride, q4, z, 1) : zero;
+    const float4 c2 = z > 2 * SLAB_CHUNK ? slab_chunk4(slabs, slab_stride, q4, z, 2) : zero;
+    const float4 c3 = z > 3 * SLAB_CHUNK ? slab_chunk4(slabs, slab_stride, q4, z, 3) : zero;
+    return slab_combine4(c0, c1, c2, c3);
 }
 
 // sum the reduction slabs of the conv weight + bias gradients into the flat gradient (fixed order)
@@ -2981,60 +3000,68 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 static_assert(OFF_W2 % 4 == 0 && OFF_W3 % 4 == 0 && CONV_PARAMS % 4 == 0, "slab regions are float4 aligned");
 
 // TF ApplyAdam, fp32, float4 wide: THE Adam launch -- of the fused step (single GPU: the conv gradients are still spread over the
-// reduction slabs and are summed here, in slab order; W_fc1 has been updated by the AdamSpan riding in the conv3 backward launch and
-// is skipped: tail0) and of fb_qnet_apply_adam (data parallel: a complete flat gradient, no slabs, tail0 = the start of W_fc1).
+// reduction slabs and are summed here, in the canonical order above; W_fc1 has been updated by the AdamSpan riding in the conv backward
+// launch and is skipped: tail0) and of fb_qnet_apply_adam (data parallel: a complete flat gradient, no slabs, tail0 = the start of W_fc1).
 // adam4 per element either way, dealt out so that the update of W_conv2 / W_conv3 leaves their split planes behind (forward
 // [k / 8][plane][co] and transposed [tap * 8 + co / 8][plane][ci], what wsplit_item builds) the way the update of W_conv1 always has
 // (split_w1).  INVARIANT this establishes: the conv planes of a net are current after every library call that writes its parameters
 // (Adam here; init / load / target sync re-split eagerly) -- so the kernels that read them in the launch they run in (the ring-fed
 // train trunk conv23_t_kernel<ring>, the fused acting trunk) need no launch in front of them.  W_fc1's planes stay stale (wver): only
 // the >= 256-state forward reads them, and the launch in front of its fc1 re-splits them on sight.
-//   workgroups [0, 32)      W_conv2, one tile of 16 k-rows x 64 co each (1024 weights): update, park the new values in LDS, emit the
-//                           2 x 64 forward entries and the 16 x 8 transposed entries (8 weights each, three planes)
-//   workgroups [32, 68)     W_conv3 likewise (36 tiles)
+//   workgroups [0, 64)      W_conv2, one tile of 8 k-rows x 64 co each (128 float4): TWO lanes per float4, lane c sums the slab chunks c and
+//                           c + 2 (the launch is a chain of dependent round trips -- P / m / v and the chunks all leave in the first one);
+//                           update, park the new values in LDS, emit the 64 forward entries and the 8 x 8 transposed entries (8 weights
+//                           each, three planes)
+//   workgroups [64, 136)    W_conv3 likewise (72 tiles)
 //   then n_rest             everything else from tail0 on: W_conv1 + b_conv1 (W_conv1's planes via split_w1), b_conv2, b_conv3, [W_fc1,]
-//                           b_fc1 and the head
+//                           b_fc1 and the head; `lanes` (4 with slabs: one chunk per lane; 1 without) lanes per float4
 //   then                    fb_train_steps' gather rider, if any
-constexpr int ADAMF_T2 = 32, ADAMF_T3 = 36;
+constexpr int ADAMF_T2 = 64, ADAMF_T3 = 72;
 struct AdamFused {
     float *p, *m, *v; const float *g; long long n; AdamDev *ad;
     const float *slabs; size_t slab_stride; int z1, z2, z3;
     uint16_t *w1s; uint4 *wsp; int FC;
     int tail0;                       // first float4 behind W_fc1
     int n_rest;                      // workgroups of the third role
+    int lanes;                       // lanes per float4 in the third role: 4 (slab mode: a chunk each) or 1
 };
+__device__ __forceinline__ float4 shfl4(float4 v, int src) { return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)); }
 __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRider gr) {
-    __shared__ float tile[16][68];
-    const int bid = blockIdx.x, tid = threadIdx.x;
+    __shared__ float tile[8][68];
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n_adam = ADAMF_T2 + ADAMF_T3 + a.n_rest;
     if (bid >= n_adam) {
         gather_body<false>(gr.c, gr.steps, gr.B, gr.idx, (uint4 *)gr.s, (uint4 *)gr.s2, gr.a, gr.r, gr.t, (long long)(bid - n_adam) * 256 + tid);
         return;
     }
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
-    auto update = [&](long long q, int z) {          // float4 q of the flat vector; z > 0: its gradient is the sum of z slabs, in slab order
-        float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
-        float4 Gv;
-        if (z > 0) Gv = slab_sum4(a.slabs, a.slab_stride, q, z);
-        else Gv = reinterpret_cast<const float4 *>(a.g)[q];
-        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
-        reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
-        return P;
-    };
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bid < ADAMF_T2 + ADAMF_T3) {
         const bool l3 = bid >= ADAMF_T2;
-        const int k0 = 16 * (l3 ? bid - ADAMF_T2 : bid), woff = l3 ? OFF_W3 : OFF_W2, CI = l3 ? 64 : 32;
-        const int kr = tid >> 4, c4 = tid & 15;
-        const float4 P = update((woff + (k0 + kr) * 64 + 4 * c4) >> 2, l3 ? a.z3 : a.z2);
-        *reinterpret_cast<float4 *>(&tile[kr][4 * c4]) = P;
+        const int k0 = 8 * (l3 ? bid - ADAMF_T2 : bid), woff = l3 ? OFF_W3 : OFF_W2, CI = l3 ? 64 : 32, z = l3 ? a.z3 : a.z2;
+        const int f = tid >> 1, c = tid & 1, kr = f >> 4, c4 = f & 15;
+        const long long q = (woff + (k0 + kr) * 64 + 4 * c4) >> 2;
+        float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
+        float4 Gv;
+        if (z > 0) {
+            // lane c: chunks c and c + 2; the pair exchanges them and both add in the canonical order
+            const float4 ca = slab_chunk4(a.slabs, a.slab_stride, q, z, c);
+            const float4 cb = z > 2 * SLAB_CHUNK ? slab_chunk4(a.slabs, a.slab_stride, q, z, c + 2) : zero;
+            const float4 oa = shfl4(ca, lane ^ 1), ob = shfl4(cb, lane ^ 1);
+            Gv = c == 0 ? slab_combine4(ca, oa, cb, ob) : slab_combine4(oa, ca, ob, cb);
+        } else Gv = reinterpret_cast<const float4 *>(a.g)[q];
+        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
+        if (c == 0) {
+            reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
+            *reinterpret_cast<float4 *>(&tile[kr][4 * c4]) = P;
+        }
         __syncthreads();
-        if (tid < 128) {                                                 // forward planes: entry (k8, col) = weights W[8 k8 .. 8 k8 + 7][col]
-            const int k8l = tid >> 6, col = tid & 63;
-            uint4 *o = a.wsp + (l3 ? WSP_W3 : WSP_W2) + (size_t)(k0 / 8 + k8l) * 3 * 64 + col;
-            const float (*t)[68] = &tile[8 * k8l];
-            wsplit_store(o, 64, t[0][col], t[1][col], t[2][col], t[3][col], t[4][col], t[5][col], t[6][col], t[7][col]);
-        } else {                                                         // transposed planes: entry (tap * 8 + co / 8, ci) = 8 consecutive co of row (tap, ci)
-            const int r = (tid - 128) >> 3, co8 = tid & 7, tap = k0 / CI, ci = k0 - tap * CI + r;
+        if (tid < 64) {                                                  // forward planes: entry (k8, col) = weights W[8 k8 .. 8 k8 + 7][col]
+            const int col = tid;
+            uint4 *o = a.wsp + (l3 ? WSP_W3 : WSP_W2) + (size_t)(k0 / 8) * 3 * 64 + col;
+            wsplit_store(o, 64, tile[0][col], tile[1][col], tile[2][col], tile[3][col], tile[4][col], tile[5][col], tile[6][col], tile[7][col]);
+        } else if (tid < 128) {                                          // transposed planes: entry (tap * 8 + co / 8, ci) = 8 consecutive co of row (tap, ci)
+            const int r = (tid - 64) >> 3, co8 = tid & 7, tap = k0 / CI, ci = k0 - tap * CI + r;
             uint4 *o = a.wsp + (l3 ? wsp_w3t(a.FC) : wsp_w2t(a.FC)) + (size_t)(tap * 8 + co8) * 3 * CI + ci;
             const float *t = &tile[r][8 * co8];
             wsplit_store(o, CI, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
@@ -3044,16 +3071,32 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     // the rest, as consecutive float4 ranges of the flat vector: [0, OFF_W2) [OFF_B2, OFF_W3) [OFF_B3, OFF_WF1) [tail0 * 4, n)
     const int n0 = OFF_W2 / 4, n1 = (OFF_W3 - OFF_B2) / 4, n2 = (OFF_WF1 - OFF_B3) / 4;
     const long long n4 = a.n >> 2, nq = n0 + n1 + n2 + (n4 - a.tail0);
-    for (long long qq = (long long)(bid - ADAMF_T2 - ADAMF_T3) * 256 + tid; qq < nq; qq += (long long)a.n_rest * 256) {
+    const int L = a.lanes, per = 256 / L, c = tid & (L - 1);              // L lanes per float4 (a power of two); lane c: slab chunk c
+    for (long long base = (long long)(bid - ADAMF_T2 - ADAMF_T3) * per; base < nq; base += (long long)a.n_rest * per) {
+        const long long qq = base + tid / L;
+        const bool live = qq < nq;
+        const long long qc = live ? qq : 0;
         long long q; int z;
-        if (qq < n0) { q = qq; z = a.z1; }
-        else if (qq < n0 + n1) { q = OFF_B2 / 4 + (qq - n0); z = a.z2; }
-        else if (qq < n0 + n1 + n2) { q = OFF_B3 / 4 + (qq - n0 - n1); z = a.z3; }
-        else { q = a.tail0 + (qq - n0 - n1 - n2); z = 0; }
-        const float4 P = update(q, z);
-        if (q * 4 < OFF_B1) {                                            // W_conv1 changed: refresh its two fp16 planes
-            const int idx = (int)q * 4;
-            split_w1(P.x, idx, a.w1s); split_w1(P.y, idx + 1, a.w1s); split_w1(P.z, idx + 2, a.w1s); split_w1(P.w, idx + 3, a.w1s);
+        if (qc < n0) { q = qc; z = a.z1; }
+        else if (qc < n0 + n1) { q = OFF_B2 / 4 + (qc - n0); z = a.z2; }
+        else if (qc < n0 + n1 + n2) { q = OFF_B3 / 4 + (qc - n0 - n1); z = a.z3; }
+        else { q = a.tail0 + (qc - n0 - n1 - n2); z = 0; }
+        float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
+        float4 Gv;
+        if (L == 4) {
+            // (z is uniform over the four lanes of an item; the shuffles run for every lane of the wave)
+            const float4 mine = z > c * SLAB_CHUNK ? slab_chunk4(a.slabs, a.slab_stride, q, z, c) : zero;
+            const int l0 = lane & ~3;
+            const float4 c0 = shfl4(mine, l0), c1 = shfl4(mine, l0 + 1), c2 = shfl4(mine, l0 + 2), c3 = shfl4(mine, l0 + 3);
+            Gv = z > 0 ? slab_combine4(c0, c1, c2, c3) : reinterpret_cast<const float4 *>(a.g)[q];
+        } else Gv = z > 0 ? slab_sum4(a.slabs, a.slab_stride, q, z) : reinterpret_cast<const float4 *>(a.g)[q];
+        adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
+        if (live && c == 0) {
+            reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
+            if (q * 4 < OFF_B1) {                                        // W_conv1 changed: refresh its two fp16 planes
+                const int idx = (int)q * 4;
+                split_w1(P.x, idx, a.w1s); split_w1(P.y, idx + 1, a.w1s); split_w1(P.z, idx + 2, a.w1s); split_w1(P.w, idx + 3, a.w1s);
+            }
         }
     }
     // the update consumes the pending tick and makes a new parameter version, of which the conv planes are current (nothing in this
@@ -3575,7 +3618,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             af.slabs = h->slabs; af.slab_stride = ss; af.z1 = z1; af.z2 = z2; af.z3 = z3;
             af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = FC; af.tail0 = span1;
             const long long nrest4 = OFF_W2 / 4 + (OFF_W3 - OFF_B2) / 4 + (OFF_WF1 - OFF_B3) / 4 + (h->n / 4 - span1);
-            af.n_rest = (int)((nrest4 + 255) / 256);
+            af.lanes = 4;                                    // slab mode: one chunk of <= 16 slabs per lane
+            af.n_rest = (int)((nrest4 * af.lanes + 255) / 256);
             hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest + ngb), dim3(256), 0, st, af, gr);
         }
     }
@@ -3660,7 +3704,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     af.p = h->params[0]; af.m = h->adam_m; af.v = h->adam_v; af.g = flat_grad; af.n = h->n; af.ad = h->adam;
     af.slabs = nullptr; af.slab_stride = 0; af.z1 = af.z2 = af.z3 = 0;
     af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = h->FC; af.tail0 = OFF_WF1 / 4;
-    af.n_rest = ADAM_GRID;
+    af.n_rest = ADAM_GRID; af.lanes = 1;
     hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest), dim3(256), 0, st, af, FbGatherRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;

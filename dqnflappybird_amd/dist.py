@@ -186,6 +186,12 @@ class NativeDP:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
+    def all_reduce(self, flat):
+        """the collective alone (sum, in place) on torch's current stream"""
+        from . import _lib as L
+        L.check(L.lib().fb_dist_all_reduce(self.handle, L.ptr(flat), flat.numel(), L.current_stream()), "fb_dist_all_reduce")
+        return flat
+
     def close(self):
         if self.handle:
             from . import _lib as L

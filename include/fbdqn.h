@@ -380,6 +380,9 @@ int fb_vec_step_dp(fb_dist_t d, fb_env_t env, fb_replay_t replay, fb_qnet_t net,
  * fb_qnet_set_grad_event(net, fb_dist_grad_event(d)). */
 int fb_dist_reduce_apply(fb_dist_t d, fb_qnet_t net, float *flat_grad /*[dev]*/, int mean_loss, void *stream);
 void *fb_dist_grad_event(fb_dist_t d);
+/* The collective alone: sum all-reduce of buf[count] (f32, [dev], in place) over the communicator, on `stream`.  For measurement
+ * (bench.py config.allreduce_us) and for callers that schedule their own step. */
+int fb_dist_all_reduce(fb_dist_t d, float *buf, int64_t count, void *stream);
 
 /* n_steps x (fb_replay_sample -> fb_replay_gather -> fb_qnet_train_step) on a uniform memory in ONE call, same results: only
  * the first draw and the first gather are launches of their own, the draw of step i + 1 rides in step i's conv3 backward
