@@ -28,6 +28,23 @@ int fb_set_error(int code, const char *fmt, ...);
 
 static inline hipStream_t fb_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Hand-offs between kernels of two streams through device words (fb_vec_step's split schedule).  A word only ever grows (the step
+// number).  Stores and polls are relaxed agent-scope atomics (they go to the coherent level, past the XCD's own L2); a reader that goes
+// on to READ what the other kernel wrote adds fb_flag_acquire() -- the L2s of the eight XCDs are not coherent with each other inside a
+// launch -- and the writer of such data stores the word from a kernel BEHIND the one that wrote the data (its end-of-kernel release has
+// written the data back).  Waits are bounded: after ~0.2 s a wave counts a timeout and goes on, so none can spin forever.
+__device__ __forceinline__ unsigned long long fb_flag_load(const unsigned long long *flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fb_flag_store(unsigned long long *flag, unsigned long long v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fb_flag_acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+__device__ __forceinline__ void fb_flag_wait(const unsigned long long *flag, unsigned long long v, unsigned *timeouts) {
+    if (fb_flag_load(flag) >= v) return;
+    const long long t0 = wall_clock64();
+    while (fb_flag_load(flag) < v) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 20000000LL) { atomicAdd(timeouts, 1u); break; }      // (100 MHz counter)
+    }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // This framework's own counter-based stream (the reference has a single env and
 // a single shared MT19937): key = seed, counter = (entity id, draw counter, stream id, 0).
@@ -58,7 +75,11 @@ __host__ __device__ static inline fb_u4 fb_philox(uint32_t k0, uint32_t k1, uint
 struct FbMT { uint32_t mt[624]; uint32_t idx; };
 
 // what a draw needs: the generator, the population size n = len(memory) at the time of the call, an error flag
-struct FbSampleCtx { FbMT *mt; int *error; long long n; };
+// gate (split schedule of fb_vec_step, or NULL): the draw is that step's first launch on the caller's stream (it stores c_entry = gate_val
+// on arrival), and when none of the drawn positions is >= newest_from -- the minibatch touches nothing the env step running beside the
+// draw is still writing -- it stores clean = gate_val
+struct FbSplitFlags;
+struct FbSampleCtx { FbMT *mt; int *error; long long n; FbSplitFlags *gate; unsigned long long gate_val; long long newest_from; };
 // random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
 struct FbSampleRider { FbSampleCtx ctx; int k; long long setsize; long long *out; };
 // fc2 / dueling head + epsilon-greedy action of one state from the fc1 partial sums (fb_head.h): the acting path's last
@@ -84,8 +105,32 @@ int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a,
 // fb_qnet_train_step on such a minibatch (isw / abs_err: the prioritized step's importance weights in, |TD errors| out; else NULL).  The split conv planes of both nets must be current: true
 // after an acting forward of >= 256 states in the same stream order (fb_vec_step), which is the only caller.
 // rider: random.sample for the NEXT step in the conv3 backward launch (fb_train_steps), or NULL.
+// split (the split schedule's train chain, or NULL): the trunk waits at the gate, the conv backward launch (W_fc1's Adam span rides there) for
+// ev_trunk, the Adam launch for ev_fc1, and the Adam launch's last workgroup stores adone
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, const float *isw, double gamma, float *loss,
-                            float *abs_err, float *flat_grad, void *stream, const FbSampleRider *rider = nullptr);
+                            float *abs_err, float *flat_grad, void *stream, const FbSampleRider *rider = nullptr, const struct FbSplitCtx *split = nullptr);
+// The split schedule of fb_vec_step (fb_common.hip): the train step of a vector step on a stream of its own BESIDE the acting forward and
+// the env step -- both read the weights the previous step's Adam left; only the replay push connects them, and only when the minibatch
+// holds one of the transitions this very step appends (the sampler decides that on the device and opens `gate` itself when it does not).
+struct FbSplitFlags {                          // [dev], one word per 64 bytes; each holds the number of the last step that reached the point
+    unsigned long long c_entry, p0[7];         // the caller's stream has reached this step's first launch (the draw): all it held before is done
+    unsigned long long clean, p1[7];           // the draw of this step holds none of the transitions the step appends
+    unsigned long long trunk_done, p2[7];      // the acting trunk has retired (stored by the fc1 launch behind it)
+    unsigned long long fc1_done, p3[7];        // the acting forward's fc1 launch has retired
+    unsigned long long env_done, p4[7];        // the env step (with the push and the head riding in it) has retired
+    unsigned clean_count, timeouts;            // minibatches that started beside their env step; waits that gave up (must stay 0)
+};
+struct FbSplitCtx {
+    hipStream_t tstream;                       // the side stream: acting forward + env step (the train chain stays on the caller's stream)
+    FbSplitFlags *f;
+    unsigned long long seq;                    // steps issued so far
+};
+FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h);    // created on first use; NULL when the runtime lacks stream memory operations (the caller falls back)
+// random.sample(range(n after the coming push), batch) -> idx on `stream`, opening ctx->gate at ctx->seq when the draw is clean; 1 when launched
+int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream);
+// one-wave launches on `stream`: wait until *flag >= v (bounded) / *flag = v behind whatever the stream holds
+int fb_split_wait(const FbSplitCtx *ctx, const unsigned long long *flag, unsigned long long v, void *stream);
+int fb_split_set(const FbSplitCtx *ctx, unsigned long long *flag, unsigned long long v, void *stream);
 int fb_qnet_refresh_planes(fb_qnet_t h, void *stream);      // re-split whichever net's planes are stale (decided on the device)
 int fb_qnet_profile_ring(fb_qnet_t h, int kernel, int reps, int algo, int batch, const FbRingSrc *ring, float *loss, void *stream);
 // Memory append as a rider of the env step: every env workgroup stores its new frame / action / reward / terminal straight
@@ -110,8 +155,10 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream);
 int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32, void *stream);      // Memory.sample behind that store, on the same stream; 1 when issued      // the tree part of the coming push, ahead of it on a side stream (see fb_replay.hip)
 int fb_env_can_carry_head(fb_env_t h);        // 1 when an env workgroup of the step launch has a wave per env it walks (<= 4 envs per workgroup)
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
+// split (or NULL): the split schedule's context -- five states per trunk workgroup (1024 envs: 205 workgroups, a fifth of the chip left to the
+// train chain), ev_trunk / ev_fc1 recorded behind the trunk / the fc1 launch
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
-                          uint8_t *actions, FbHeadRider *head, void *stream);
+                          uint8_t *actions, FbHeadRider *head, void *stream, const FbSplitCtx *split = nullptr);
 // the rider for the frame / scalar part of "fb_replay_push" (returns 1, fills *push and COUNTS the push: the env launch that carries it
 // must follow, and fb_replay_finish_push behind that launch: Memory.store's tree update of a prioritized memory -- joined if it ran
 // ahead on the side stream, launched otherwise; nothing for a uniform memory)

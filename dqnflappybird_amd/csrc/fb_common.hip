@@ -7,6 +7,7 @@
 #include "fb_common.h"
 
 thread_local char fb_err_buf[512] = "";
+unsigned long long fb_api_epoch = 0;
 
 int fb_set_error(int code, const char *fmt, ...) {
     va_list ap;
@@ -152,6 +153,58 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     {
         const int rc0 = fb_qnet_check_step(net, n_envs, train ? batch : -1);
         if (rc0 != FB_OK) return rc0;
+    }
+    // ---- The split schedule (uniform memory, small batches): act(k) and train(k) of the reference's loop BOTH read the weights Adam(k - 1)
+    // left -- what orders them is the replay append between them (FlappyBirdDQN.py:72-76, BrainDQN.py:236-240), and that only matters when
+    // the minibatch holds one of the n_envs transitions this very step appends (32 draws from a million slots: ~3 % of the steps).  So
+    // the train chain goes to a stream of its own: the draw (its population size is known on the host) decides on the device whether it is
+    // clean and, if so, opens the gate the chain waits at -- otherwise the caller's stream opens it behind the env step, and the step runs
+    // in the old order.  Same kernels, same inputs, same results bit for bit (the tests that pin fb_vec_step to the separate calls run
+    // through here); the acting trunk takes five states per workgroup so that a fifth of the chip is free for the chain beside it.
+    // Hazards between the two streams, and what covers each: W_fc1's Adam span (conv backward launch) against the trunk's riding re-split
+    // of W_fc1's planes -> that launch waits for the trunk; the Adam launch (conv planes, biases, head parameters, the version word)
+    // against the trunk and the fc1 launch (which records the version and copies the head's parameters for the env launch's head rider)
+    // -> it waits for the fc1 launch; workspaces -> the fused acting forward has its own (hf_act / hp_act); the acting forward against
+    // the previous step's Adam, and against whatever else the caller's stream held at entry -> ev_entry.
+    static const bool split_on = !(getenv("FB_VEC_SPLIT") && atoi(getenv("FB_VEC_SPLIT")) == 0);      // A/B knob: 0 = one stream
+    if (split_on && train && !per && !b->flat_grad && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
+        hipStream_t A = reinterpret_cast<hipStream_t>(stream);       // (not fb_stream(): the light-entry test below compares fb_api_epoch with its value at the last exit)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(A, &cap);
+        FbSampleRider probe;
+        FbSplitCtx *sc = cap == hipStreamCaptureStatusNone && fb_replay_sample_rider(replay, batch, b->idx, &probe) ? fb_qnet_split_ctx(net) : nullptr;
+        if (sc) {
+            // Which chain goes where: the TRAIN chain stays on the caller's stream -- it is the longer one, step k + 1's follows step k's
+            // in stream order with no hop, and whatever the caller puts on `stream` between calls (a target sync, reads of idx / loss) is
+            // ordered against it for free.  Acting + env go to the net's side stream S.
+            // How the chains hand over: through device words, not events -- a cross-stream event costs 6 - 13 us per use on this part even
+            // when it has long been signalled (tools/mb/mb_gate.hip, profiles/r04_notes.md), a word that a kernel stores and another polls
+            // ~1 (FbSplitFlags; every wait is bounded):
+            //   S's first launch is one wave waiting for c_entry: the draw -- this call's first launch on `stream` -- has started, so the
+            //     previous Adam and everything else the caller's stream held are done (its reads of the previous step's rewards included);
+            //   the acting forward's fc1 launch stores trunk_done, a one-thread launch behind it fc1_done, one behind the env launch env_done;
+            //   the train trunk waits for env_done (of the previous step: nothing else orders `stream` behind that push; of this step
+            //     when the draw was not clean), the Adam span's stores for trunk_done, the Adam launch's stores for fc1_done, and the
+            //     Adam launch does not retire before env_done: on return every result of the step is ordered on `stream` as before.
+            hipStream_t C = A, S = sc->tstream;
+            FbSplitFlags *F = sc->f;
+            sc->seq += 1;
+            int rc = fb_split_wait(sc, &F->c_entry, sc->seq, S);
+            FbHeadRider hrider;
+            if (rc == FB_OK) rc = fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, S, sc);
+            if (rc == FB_OK) rc = fb_split_set(sc, &F->fc1_done, sc->seq, S);
+            // (a failure from here on leaves waits behind that nothing will satisfy: they give up after 0.2 s each, the error is returned)
+            if (rc != FB_OK) { (void)fb_split_set(sc, &F->c_entry, sc->seq, C); (void)hipStreamSynchronize(S); return rc; }
+            if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C)) return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched");
+            FbPushRider prider;
+            fb_replay_begin_push_rider(replay, &prider);       // (counts the push: the minibatch below is addressed in the memory as it will be)
+            FbRingSrc ring;
+            rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
+            if (rc == FB_OK) rc = fb_qnet_train_step_ring(net, algo, batch, &ring, nullptr, gamma, b->loss, nullptr, nullptr, C, nullptr, sc);
+            const int rc2 = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, nullptr, &prider, &hrider, S);
+            const int rc3 = fb_split_set(sc, &F->env_done, sc->seq, S);
+            return rc != FB_OK ? rc : rc2 != FB_OK ? rc2 : rc3;
+        }
     }
     // prioritized memory: Memory.store's tree update of this step's push goes out FIRST, on the memory's side stream -- it depends on the
     // tree as the previous step left it and on the env count, nothing else -- and runs beside the acting forward and the env step

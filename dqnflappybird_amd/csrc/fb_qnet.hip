@@ -649,12 +649,15 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
         const uint4 *w1g = reinterpret_cast<const uint4 *>(a.w1s);
         const uint4 wc0 = w1g[threadIdx.x], wc1 = w1g[threadIdx.x + 512], wc2 = w1g[threadIdx.x + 1024], wc3 = w1g[threadIdx.x + 1536];
         const uint4 *ng = reinterpret_cast<const uint4 *>(a.nib + (size_t)s0 * FB_NIB_STRIDE);
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 512;            // (SPW * NIB_U4 = 928 entries: two per thread)
-        static_assert(SPW * NIB_U4 <= 1024, "two image entries per thread");
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 512, i2 = threadIdx.x + 1024;      // (SPW * NIB_U4 = 928 entries at SPW = 4: two per thread; 1160 at 5: three)
+        static_assert(SPW * NIB_U4 <= 1536, "at most three image entries per thread");
         const uint4 n0 = ng[i0 < nloc * NIB_U4 ? i0 : 0], n1 = ng[i1 < nloc * NIB_U4 ? i1 : 0];
+        uint4 n2 = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SPW * NIB_U4 > 1024) n2 = ng[i2 < nloc * NIB_U4 ? i2 : 0];
         smem[XCH + threadIdx.x] = wc0; smem[XCH + threadIdx.x + 512] = wc1; smem[XCH + threadIdx.x + 1024] = wc2; smem[XCH + threadIdx.x + 1536] = wc3;
         if (i0 < SPW * NIB_U4) smem[NIBO + i0] = i0 < nloc * NIB_U4 ? n0 : make_uint4(0u, 0u, 0u, 0u);
         if (i1 < SPW * NIB_U4) smem[NIBO + i1] = i1 < nloc * NIB_U4 ? n1 : make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SPW * NIB_U4 > 1024) { if (i2 < SPW * NIB_U4) smem[NIBO + i2] = i2 < nloc * NIB_U4 ? n2 : make_uint4(0u, 0u, 0u, 0u); }
         if (threadIdx.x < 256) smem[LUTO + threadIdx.x] = nib_lut_entry(threadIdx.x);
         if (threadIdx.x < 16) smem[ZOFF + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
         if (nloc < SPW)                          // the last workgroup of a count that SPW does not divide: rows of absent states compute on zeros
@@ -888,6 +891,7 @@ struct C23T {
     FbRingSrc ring; float *p1o; uint8_t *amax; unsigned long long *ring_fo;
     uint16_t *a3s; size_t pl3;               // conv3's output as planes too ([plane][row * 25 + pixel][64]) when fc1_sp_kernel follows, or NULL
     unsigned *ovf;                           // the net's overflow word (note_overflow)
+    FbSplitFlags *gate; unsigned long long gate_val;      // split schedule (or NULL): nothing of the ring is read before the env steps it may depend on have retired
 };
 
 // RING = true: conv1 of the state in front of conv2 + conv3, fed from the replay's 1-bit frame ring.  The workgroup locates its
@@ -954,6 +958,13 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         const uint4 wc0 = w1g[t5], wc1 = w1g[t5 + 512], wc2 = w1g[t5 + 1024], wc3 = w1g[t5 + 1536];
         // ---- where the state lives: frames tt - 3 + fshift .. of env e (four threads, one frame offset each)
         if (tid < 4) {
+            // split schedule: the minibatch may hold a transition the env step running beside this launch is still appending -- the draw
+            // opened the gate if it does not, the env step's stream opens it otherwise (every other thread meets these four at the barrier)
+            // (the previous step's env launch in any case: nothing else orders this stream behind it)
+            if (a.gate) {
+                fb_flag_wait(&a.gate->env_done, fb_flag_load(&a.gate->clean) == a.gate_val ? a.gate_val - 1 : a.gate_val, &a.gate->timeouts);
+                fb_flag_acquire();
+            }
             long long tt; int e;
             fb_ring_locate(a.ring.c, a.ring.steps, a.ring.idx[blockIdx.x], tid == 0 && blockIdx.y == 0, tt, e);
             const unsigned long long o = fb_frame_off(a.ring.c, tt - 3 + s.fshift + tid, e);
@@ -1126,7 +1137,9 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
 constexpr int FC1_SP_KS = 4;
 struct Fc1Args { const uint16_t *ain; size_t aplane; const uint16_t *zeros; const uint4 *w; float *hfp; int stot, M, N;
                  const unsigned *pver; unsigned *wver;          // (behind the fused acting trunk, which re-split W_fc1's planes if they were stale: record it)
-                 const uint4 *w2; int m_split; };               // rows from m_split on (a multiple of the 128-row tile) take the weights w2: the target net's slices in the same launch
+                 const uint4 *w2; int m_split;                  // rows from m_split on (a multiple of the 128-row tile) take the weights w2: the target net's slices in the same launch
+                 const float *hp_src; float *hp_dst; int hp_n;      // the fused acting forward: the parameters its head will read (b_fc1 on), copied for it here
+                 unsigned long long *set_flag; unsigned long long set_val; };   // split schedule (or NULL): this launch has started, so the trunk in front of it has retired
 
 // ablation switch (tools/abl_forward.sh; 0 = the product): 1 no global loads inside the chunk loop, 2 no MFMAs, 3 no ring writes / fragment
 // reads (no LDS traffic in the loop), 4 no output stores
@@ -1140,6 +1153,8 @@ __global__ __launch_bounds__(256) void fc1_sp_kernel(Fc1Args a) {
     __shared__ uint4 smem[3 * SLOT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, j = lane & 31;
     if (a.wver && blockIdx.x == 0 && threadIdx.x == 0) *a.wver = *a.pver;
+    if (a.hp_dst) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < a.hp_n) a.hp_dst[i] = a.hp_src[i]; }
+    if (a.set_flag && blockIdx.x == 0 && threadIdx.x == 0) fb_flag_store(a.set_flag, a.set_val);
     // XCD-aware tile order (consecutive workgroup ids go round the 8 XCDs, each with its own 4 MB L2): XCD x takes K slice
     // x & 3 and the column tiles of half x >> 2, for every row tile -- 0.6 MB of weights + 2.4 MB of activations per L2
     // instead of all 4.9 MB of weights behind each one (row-tile-major order: 49 MB through the fabric per 1024 states)
@@ -2311,12 +2326,16 @@ __device__ __forceinline__ void adam4(float4 &P, float4 &Mv, float4 &V, const fl
 // that follow (conv3 / conv2 / conv1 backward) neither read W_fc1 nor fill more than ~200 of the 256 CUs, and wait on
 // latency rather than on HBM.  Its Adam update therefore rides as extra workgroups at the END of the conv3 backward
 // launch (float4 range [q0, q1) of the flat parameter vector); adam_fused_kernel at the end of the step skips that range.
-struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; };
+// wait_flag (split schedule, or NULL): nothing is STORED before *wait_flag >= wait_val -- the acting trunk running beside this launch on
+// another stream re-splits W_fc1's planes from these very parameters in its first microseconds (the loads do not wait)
+struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; const unsigned long long *wait_flag; unsigned long long wait_val; unsigned *timeouts; };
 __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan a) {
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
+    bool open = !a.wait_flag || fb_flag_load(a.wait_flag) >= a.wait_val;
     for (int q = a.q0 + blk * (int)blockDim.x + (int)threadIdx.x; q < a.q1; q += nblk * (int)blockDim.x) {
         float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
         adam4(P, Mv, V, reinterpret_cast<const float4 *>(a.g)[q], alpha, omb1, omb2, eps);
+        if (!open) { fb_flag_wait(a.wait_flag, a.wait_val, a.timeouts); open = true; }
         reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
     }
 }
@@ -3024,7 +3043,14 @@ struct AdamFused {
     int tail0;                       // first float4 behind W_fc1
     int n_rest;                      // workgroups of the third role
     int lanes;                       // lanes per float4 in the third role: 4 (slab mode: a chunk each) or 1
+    // split schedule (or NULL): nothing is STORED before the acting forward's fc1 launch on the other stream has retired (it reads the conv
+    // planes and biases, records the version word and copies the head's parameters); and the launch does not retire before that
+    // stream's env step has (whatever the caller puts on this stream next may read the env step's outputs)
+    FbSplitFlags *split; unsigned long long split_val;
 };
+__device__ __forceinline__ void adam_store_gate(const AdamFused &a, bool &open) {
+    if (!open) { fb_flag_wait(&a.split->fc1_done, a.split_val, &a.split->timeouts); open = true; }
+}
 __device__ __forceinline__ float4 shfl4(float4 v, int src) { return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)); }
 __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRider gr) {
     __shared__ float tile[8][68];
@@ -3036,6 +3062,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     }
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool open = !a.split || fb_flag_load(&a.split->fc1_done) >= a.split_val;
     if (bid < ADAMF_T2 + ADAMF_T3) {
         const bool l3 = bid >= ADAMF_T2;
         const int k0 = 8 * (l3 ? bid - ADAMF_T2 : bid), woff = l3 ? OFF_W3 : OFF_W2, CI = l3 ? 64 : 32, z = l3 ? a.z3 : a.z2;
@@ -3051,6 +3078,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
             Gv = c == 0 ? slab_combine4(ca, oa, cb, ob) : slab_combine4(oa, ca, ob, cb);
         } else Gv = reinterpret_cast<const float4 *>(a.g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
+        adam_store_gate(a, open);
         if (c == 0) {
             reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
             *reinterpret_cast<float4 *>(&tile[kr][4 * c4]) = P;
@@ -3091,6 +3119,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
             Gv = z > 0 ? slab_combine4(c0, c1, c2, c3) : reinterpret_cast<const float4 *>(a.g)[q];
         } else Gv = z > 0 ? slab_sum4(a.slabs, a.slab_stride, q, z) : reinterpret_cast<const float4 *>(a.g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
+        adam_store_gate(a, open);
         if (live && c == 0) {
             reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
             if (q * 4 < OFF_B1) {                                        // W_conv1 changed: refresh its two fp16 planes
@@ -3101,6 +3130,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     }
     // the update consumes the pending tick and makes a new parameter version, of which the conv planes are current (nothing in this
     // launch reads these words)
+    adam_store_gate(a, open);
     if (bid == ADAMF_T2 + ADAMF_T3 && tid == 0) { a.ad->applies = a.ad->ticks; a.ad->pver[0] += 1; a.ad->wverc[0] = a.ad->pver[0]; }
     if (bid == ADAMF_T2 + ADAMF_T3 && tid < (int)(a.n & 3)) {
         const long long q = (n4 << 2) + tid;
@@ -3109,6 +3139,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
         a.p[q] -= (mm * alpha) / (sqrtf(vv) + eps);
         a.m[q] = mm; a.v[q] = vv;
     }
+    if (a.split && bid == ADAMF_T2 + ADAMF_T3 && tid == 0) fb_flag_wait(&a.split->env_done, a.split_val, &a.split->timeouts);
 }
 
 // tf.truncated_normal(stddev=0.01) weights, 0.01 biases (BrainDQN.py:123-152)
@@ -3160,6 +3191,11 @@ struct fb_qnet {
     float *dhf, *dh3, *dh2, *dp1;
     float *gmax;                     // large batches: the loss kernel's per-workgroup maxima of |dhf| (gradient pre-scale of fc1_bwd_big_kernel), [FC / 16]
     int zmax;
+    // the fused acting forward's OWN fc1 partial sums and its copy of the parameters the head reads (b_fc1 on: [n - off.bf1], taken by the
+    // fc1 launch): a train step running beside it on another stream (fb_vec_step's split schedule) shares none of its buffers and may
+    // start its Adam launch as soon as that fc1 launch is through
+    float *hf_act, *hp_act;
+    FbSplitCtx *split;               // fb_qnet_split_ctx
 };
 
 static NetOff make_off(int FC, int A, int dueling) {
@@ -3206,6 +3242,7 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
     alloc((void **)&h->dhf, Bm * fc_width * 4); alloc((void **)&h->dh3, Bm * 1600 * 4);
     alloc((void **)&h->dh2, Bm * 1600 * 4); alloc((void **)&h->dp1, Bm * 3200 * 4);
     alloc((void **)&h->gmax, (size_t)(fc_width / 16) * 4);
+    alloc((void **)&h->hf_act, S * fc_width * 4 * FC1_SP_KS); alloc((void **)&h->hp_act, sizeof(float) * (size_t)(h->n - h->off.bf1));
     if (e != hipSuccess) {
         fb_set_error(e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP, "fb_qnet_create: %s", hipGetErrorString(e));
         fb_qnet_destroy(h);
@@ -3223,9 +3260,57 @@ extern "C" int fb_qnet_create(int arch, int fc_width, int n_actions, int max_bat
 extern "C" int fb_qnet_destroy(fb_qnet_t h) {
     if (!h) return FB_OK;
     void *ptrs[] = {h->zeros, h->wsp[0], h->wsp[1], h->a1s, h->a3s, h->w1s[0], h->w1s[1], h->params[0], h->params[1], h->adam_m, h->adam_v, h->grad, h->slabs, h->slabs1, h->adam, h->p1, h->amax, h->h2,
-                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1, h->ring_fo, h->gmax};
+                    h->h3, h->hf, h->q, h->qpart, h->dhf, h->dh3, h->dh2, h->dp1, h->ring_fo, h->gmax, h->hf_act, h->hp_act};
+    if (h->split) {
+        FbSplitCtx *c = h->split;
+        if (c->tstream) { (void)hipStreamSynchronize(c->tstream); (void)hipStreamDestroy(c->tstream); }
+        if (c->f) (void)hipFree(c->f);
+        delete c;
+    }
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
+    return FB_OK;
+}
+
+__global__ void flag_wait_kernel(const unsigned long long *flag, unsigned long long v, unsigned *timeouts) { if (threadIdx.x == 0) fb_flag_wait(flag, v, timeouts); }
+__global__ void flag_set_kernel(unsigned long long *flag, unsigned long long v) { fb_flag_store(flag, v); }
+
+FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h) {
+    if (!h) return nullptr;
+    if (h->split) return h->split->tstream ? h->split : nullptr;
+    FbSplitCtx *c = new FbSplitCtx();
+    memset(c, 0, sizeof(*c));
+    h->split = c;                                // (kept even when incomplete: tstream == NULL means "tried, unavailable")
+    int lo = 0, hi = 0;
+    bool ok = hipMalloc((void **)&c->f, sizeof(FbSplitFlags)) == hipSuccess && hipMemset(c->f, 0, sizeof(FbSplitFlags)) == hipSuccess;
+    hipStream_t ts = nullptr;
+    ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&ts, hipStreamNonBlocking, lo) == hipSuccess;      // (lowest: the train chain beside it is the critical one)
+    if (!ok) { (void)hipGetLastError(); return nullptr; }
+    c->tstream = ts;
+    return c;
+}
+
+int fb_split_wait(const FbSplitCtx *c, const unsigned long long *flag, unsigned long long v, void *stream) {
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, fb_stream(stream), flag, v, &c->f->timeouts);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+int fb_split_set(const FbSplitCtx *, unsigned long long *flag, unsigned long long v, void *stream) {
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, fb_stream(stream), flag, v);
+    FB_LAUNCH_CHECK();
+    return FB_OK;
+}
+
+extern "C" int fb_qnet_split_stats(fb_qnet_t h, int64_t *steps_host, int64_t *clean_host) {
+    FB_REQUIRE(h && steps_host && clean_host, "fb_qnet_split_stats: NULL argument");
+    *steps_host = 0; *clean_host = 0;
+    if (!h->split || !h->split->tstream) return FB_OK;
+    FB_CHECK_HIP(hipDeviceSynchronize());
+    unsigned v[2] = {0, 0};
+    FB_CHECK_HIP(hipMemcpy(v, &h->split->f->clean_count, sizeof(v), hipMemcpyDeviceToHost));
+    FB_REQUIRE(v[1] == 0, "fb_qnet_split_stats: %u wait(s) between the two chains of the split schedule gave up after 0.2 s: the results of those steps are not to be trusted", v[1]);
+    *steps_host = (int64_t)h->split->seq; *clean_host = (int64_t)v[0];
     return FB_OK;
 }
 
@@ -3355,6 +3440,9 @@ struct Plan {
     const FbSampleRider *sample_rider;       // train plan: random.sample for the next step rides in the conv3 backward launch
     const FbGatherRider *gather_rider;       // ... and its minibatch gather in the Adam launch
     const FbRingSrc *ring;                   // the minibatch lives in the replay's frame ring (no gathered copies): conv trunk in one launch
+    // the split schedule.  Acting plan: five states per trunk workgroup, events behind the trunk / fc1 launches.  Train plan: the trunk
+    // waits at the gate, the conv backward launch (W_fc1's Adam span) for ev_trunk, the Adam launch for ev_fc1 and stores adone
+    const FbSplitCtx *split;
 };
 
 static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
@@ -3378,6 +3466,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     C23T c23t;
     memset(&job, 0, sizeof(job)); memset(&c23t, 0, sizeof(c23t));
     const bool trunk = p.ring != nullptr;        // ring-fed minibatch (any batch size): the whole conv trunk per state in one launch
+    bool acting_fused = false;                   // the fused acting forward ran: its fc1 partial sums are in hf_act, its head parameters in hp_act
     if (!sp || trunk) {
         job.FC = h->FC;
         c23t.sl = p.sl; c23t.p1 = h->p1; c23t.h2 = h->h2; c23t.h3 = h->h3; c23t.ovf = &h->adam->ovf;
@@ -3394,6 +3483,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     if (trunk) FB_K(K_CONV2) {                       // conv1 + pool + conv2 + conv3 of every state in ONE launch
         if (sp) { c23t.a3s = h->a3s; c23t.pl3 = pl2; }      // >= 256 states per slice: fc1_sp_kernel follows and reads conv3's output as planes
         c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
+        if (p.train && p.split && only < 0) { c23t.gate = p.split->f; c23t.gate_val = p.split->seq; }
         const bool w16 = maxc * p.ns <= 256;          // at most one workgroup per CU anyway: spend the idle SIMD slots on conv1's second round
         if (nsp == 3 && w16) hipLaunchKernelGGL((conv23_t_kernel<3, true, true>), dim3(maxc, p.ns), dim3(1024), 0, st, c23t);
         else if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
@@ -3419,7 +3509,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             const int t1p = (rows * 100 + 7) / 8, gsp = min(256, (t1p + C1_WAVES - 1) / C1_WAVES);      // one 12-wave workgroup per CU, the waves stride over the tiles
             // the acting path on nibble states: conv1 + conv2 + conv3 in ONE launch (conv23_sp_kernel<., 4, true>), four states per workgroup
             static const bool fuse_on = !(getenv("FB_ACT_FUSED") && atoi(getenv("FB_ACT_FUSED")) == 0);      // A/B knob
-            const bool fused = fuse_on && p.nib && !p.train && !trunk && z1 - z0 == 1;
+            const bool fused = fuse_on && p.nib && !p.train && !trunk && z1 - z0 == 1 && p.ns == 1;
+            acting_fused = fused;
             if (!trunk && !fused) FB_K(K_CONV1) {
                 if (p.nib) hipLaunchKernelGGL(conv1_sp_kernel<true>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side, &h->adam->ovf);
                 else hipLaunchKernelGGL(conv1_sp_kernel<false>, dim3(gsp), dim3(64 * C1_WAVES), 0, st, sl, (const uint8_t *)h->zeros, h->a1s, pl1, nsp, h->wsp[which], h->FC, pver, (const unsigned *)wver, side, &h->adam->ovf);
@@ -3427,8 +3518,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             C23Args c23{h->a1s + (size_t)row0 * 3200, pl1, h->wsp[which] + WSP_W2, s0.params + OFF_B2, s0.params + OFF_B3, h->a3s + (size_t)row0 * 1600, pl2, rows, pver, wver, only < 0 ? &h->adam->wverc[which] : nullptr,
                         p.train ? h->h2 + (size_t)row0 * 1600 : nullptr, p.train ? h->h3 + (size_t)row0 * 1600 : nullptr,
                         s0.states, s0.w1s, s0.params + OFF_B1, s0.params, h->wsp[which], h->FC, &h->adam->ovf};
-            Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, h->hf + (size_t)row0 * h->FC, stot, rows, h->FC,
-                       fused ? pver : nullptr, fused ? wver : nullptr, nullptr, 0};
+            Fc1Args af{h->a3s + (size_t)row0 * 1600, pl2, h->zeros, h->wsp[which] + WSP_WF1, (fused ? h->hf_act : h->hf) + (size_t)row0 * h->FC, stot, rows, h->FC,
+                       fused ? pver : nullptr, fused ? wver : nullptr, nullptr, 0,
+                       fused ? s0.params + h->off.bf1 : nullptr, fused ? h->hp_act : nullptr, fused ? (int)(h->n - h->off.bf1) : 0,
+                       fused && p.split && only < 0 ? &p.split->f->trunk_done : nullptr, p.split ? p.split->seq : 0};
             // behind the ring-fed trunk the groups only differ in fc1's weights: when the next group (the target net's slices) follows this
             // one row for row and starts on a tile boundary, ONE fc1 launch takes both (two launches of 128 + 64 workgroups each left
             // half the chip idle twice: 8.9 + 8.5 us at B = 256 against one of 192)
@@ -3444,13 +3537,17 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 }
             }
             const int rows_f = af.M;
-            const dim3 gc((rows + 4) / 5), gc4((rows + 3) / 4), gf(((rows_f + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
+            static const int act_spw = getenv("FB_ACT_SPW") && atoi(getenv("FB_ACT_SPW")) == 5 ? 5 : 4;      // A/B knob: states per workgroup of the fused acting trunk
+            const bool spw5 = fused && (act_spw == 5 || p.split);          // (the split schedule: 1024 envs = 205 workgroups, the rest of the chip for the train chain)
+            const dim3 gc((rows + 4) / 5), gc4(spw5 ? (rows + 4) / 5 : (rows + 3) / 4), gf(((rows_f + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
-                if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 4, true>), gc4, dim3(512), 0, st, c23); }      // conv1 .. conv3
+                if (spw5) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 5, true>), gc4, dim3(512), 0, st, c23); }
+                else if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 4, true>), gc4, dim3(512), 0, st, c23); }      // conv1 .. conv3
                 else if (!trunk) { FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<3>, gc, dim3(512), 0, st, c23); }      // conv3 rides in the same launch
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<3>, gf, dim3(256), 0, st, af);
             } else {
-                if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<1, 4, true>), gc4, dim3(512), 0, st, c23); }
+                if (spw5) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<1, 5, true>), gc4, dim3(512), 0, st, c23); }
+                else if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<1, 4, true>), gc4, dim3(512), 0, st, c23); }
                 else if (!trunk) { FB_K(K_CONV2) hipLaunchKernelGGL(conv23_sp_kernel<1>, gc, dim3(512), 0, st, c23); }
                 FB_K(K_FC1) hipLaunchKernelGGL(fc1_sp_kernel<1>, gf, dim3(256), 0, st, af);
             }
@@ -3478,11 +3575,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         HeadArgs H;
         H.sl = p.sl; H.nslices = p.ns;
         HeadCore &C = H.c;
-        C.hf = h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : 1; C.q = h->q; C.FC = h->FC; C.A = h->A;
+        C.hf = acting_fused ? h->hf_act : h->hf; C.stot = stot; C.nks = sp ? FC1_SP_KS : 1; C.q = h->q; C.FC = h->FC; C.A = h->A;
         C.dueling = h->arch == FB_ARCH_DUELING; C.off = h->off; C.actions = p.actions; C.epsilon = p.epsilon;
         C.seed_lo = (uint32_t)p.seed; C.seed_hi = (uint32_t)(p.seed >> 32);
         C.step_lo = (uint32_t)p.step; C.step_hi = (uint32_t)(p.step >> 32);
-        if (p.head_rider) { p.head_rider->c = C; p.head_rider->params = p.sl.s[0].params; p.head_rider->on = 1; }   // rides in the env launch
+        // (the rider of a fused acting forward reads the head's parameters from the copy that forward's fc1 launch took: b_fc1 on)
+        if (p.head_rider) { p.head_rider->c = C; p.head_rider->params = acting_fused ? h->hp_act - h->off.bf1 : p.sl.s[0].params; p.head_rider->on = 1; }   // rides in the env launch
         else hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
     }
     if (p.train) {
@@ -3540,8 +3638,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         // is the latency-bound chains beside it, wherever it rides -- so the default stays "all of it beside the data-gradient chain")
         static const int span_pct = getenv("FB_SPAN_SPLIT") ? atoi(getenv("FB_SPAN_SPLIT")) : 100;     // tuning knob: per cent of the span in the first launch
         const int spanm = span0 + (int)(((long long)(span1 - span0) * span_pct / 100) & ~511LL);
-        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, spanm};
-        const AdamSpan span_b{h->params[0], h->adam_m, h->adam_v, G, h->adam, spanm, span1};
+        // (split schedule: the span's stores wait for the acting trunk on the other stream, wherever the span rides)
+        const unsigned long long *swf = p.split && only < 0 ? &p.split->f->trunk_done : nullptr;
+        const unsigned long long swv = p.split ? p.split->seq : 0;
+        unsigned *swt = p.split ? &p.split->f->timeouts : nullptr;
+        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, spanm, swf, swv, swt};
+        const AdamSpan span_b{h->params[0], h->adam_m, h->adam_v, G, h->adam, spanm, span1, swf, swv, swt};
         FbSampleRider srider;
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
@@ -3562,6 +3664,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             // small batches: the whole conv backward per sample in ONE launch (conv_bw_kernel); one conv2 / conv3 slab per sample
             static const bool bw_on = !(getenv("FB_BW_MERGED") && atoi(getenv("FB_BW_MERGED")) == 0);      // A/B knob: 0 = the two-launch form
             const bool bw = bw_on && fk && B <= h->zmax;
+            // split schedule: W_fc1's Adam span rides in the next launch, and the acting trunk running beside this step on another stream
+            // re-splits W_fc1's planes from those very parameters in its first microseconds
+
             if (bw) {
                 z3 = B;
                 FB_K(K_CONV3_BWD) {
@@ -3569,7 +3674,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                     float *s1 = fold1 ? h->slabs1 : h->slabs;
                     const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
                     const dim3 g(BW_WGS * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0));
-                    const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
+                    const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1, swf, swv, swt};
                     const int n_ad = n_adam5 + n_adam5b;
                     if (h->nsplit_train == 3) {
                         if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<3, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
@@ -3607,6 +3712,8 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         const int z2 = z3;
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS / 4 + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
+        // split schedule: the Adam launch rewrites the conv planes / biases the acting trunk reads and the parameters its fc1 launch copies for the head
+
         if (p.apply_adam) FB_K(K_ADAM)
         {
             FbGatherRider gr;
@@ -3619,6 +3726,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = FC; af.tail0 = span1;
             const long long nrest4 = OFF_W2 / 4 + (OFF_W3 - OFF_B2) / 4 + (OFF_WF1 - OFF_B3) / 4 + (h->n / 4 - span1);
             af.lanes = 4;                                    // slab mode: one chunk of <= 16 slabs per lane
+            af.split = p.split && only < 0 ? p.split->f : nullptr; af.split_val = p.split ? p.split->seq : 0;
             af.n_rest = (int)((nrest4 * af.lanes + 255) / 256);
             hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest + ngb), dim3(256), 0, st, af, gr);
         }
@@ -3680,13 +3788,14 @@ int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch) {
 }
 
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
-                          uint8_t *actions, FbHeadRider *head, void *stream) {
+                          uint8_t *actions, FbHeadRider *head, void *stream, const FbSplitCtx *split) {
     FB_REQUIRE(h && nib_states && actions && head, "fb_qnet_act_nib_rider: NULL argument");
     FB_REQUIRE(n >= 1 && n <= 3 * h->max_batch, "fb_qnet_act_nib: n %d exceeds 3*max_batch", n);
     Plan p = forward_plan(h, 0, nib_states, n);
     p.nib = true;
     p.actions = actions; p.epsilon = epsilon; p.seed = seed; p.step = step;
     p.head_rider = head;
+    p.split = split;
     return run_plan(h, p, -1, fb_stream(stream));
 }
 
@@ -3705,6 +3814,7 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     af.slabs = nullptr; af.slab_stride = 0; af.z1 = af.z2 = af.z3 = 0;
     af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = h->FC; af.tail0 = OFF_WF1 / 4;
     af.n_rest = ADAM_GRID; af.lanes = 1;
+    af.split = nullptr; af.split_val = 0;
     hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest), dim3(256), 0, st, af, FbGatherRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;
@@ -3762,12 +3872,13 @@ static int train_plan(fb_qnet *h, int algo, int B, const uint8_t *s, const uint8
 }
 
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int B, const FbRingSrc *ring, const float *isw, double gamma, float *loss, float *abs_err,
-                            float *flat_grad, void *stream, const FbSampleRider *rider) {
+                            float *flat_grad, void *stream, const FbSampleRider *rider, const FbSplitCtx *split) {
     FB_REQUIRE(h && ring && ring->idx && ring->a && ring->r && ring->t, "fb_qnet_train_step_ring: NULL argument");
     Plan p;
     int rc = train_plan(h, algo, B, nullptr, ring->a, ring->r, nullptr, ring->t, isw, gamma, loss, abs_err, nullptr, flat_grad, &p, ring);
     if (rc != FB_OK) return rc;
     p.sample_rider = rider;
+    p.split = split;
     return run_plan(h, p, -1, fb_stream(stream));
 }
 

@@ -130,6 +130,13 @@ __global__ __launch_bounds__(64) void sample_cpython_kernel(ReplayParams P, int 
     sample_cpython_body(sample_ctx(P, P.dev->steps), k, setsize, out, mt, pool);
 }
 
+// the draw of a step whose push is still on its way on another stream (fb_vec_step's split schedule): population size and gate from the host
+__global__ __launch_bounds__(64) void sample_gated_kernel(FbSampleRider r) {
+    __shared__ uint32_t mt[624];
+    __shared__ int pool[FB_SAMPLE_POOL + FB_SAMPLE_TAB];
+    sample_cpython_body(r.ctx, r.k, r.setsize, r.out, mt, pool);
+}
+
 // fb_replay_push_sample: Memory append + random.sample in ONE launch.  The sample only needs the size the
 // memory will have after the push (known on the host), not the pushed data, so it rides as one extra
 // workgroup beside the copy workgroups: the ~10 us single-wave sampler leaves the step's critical path.
@@ -976,6 +983,15 @@ int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider
     rider->ctx = FbSampleCtx{P.mt, &P.dev->error, total < P.cap ? total : P.cap};
     rider->k = batch; rider->setsize = cpython_setsize(batch); rider->out = (long long *)idx;
     return 1;
+}
+
+int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream) {
+    FbSampleRider r;
+    if (!h || !ctx || !fb_replay_sample_rider(h, batch, idx, &r, 1)) return 0;
+    r.ctx.gate = ctx->f; r.ctx.gate_val = ctx->seq;
+    r.ctx.newest_from = r.ctx.n - h->P.n_envs;          // deque positions of the transitions the coming push appends
+    hipLaunchKernelGGL(sample_gated_kernel, dim3(1), dim3(64), 0, fb_stream(stream), r);
+    return hipGetLastError() == hipSuccess;
 }
 
 extern "C" int fb_replay_current_state(fb_replay_t h, uint8_t *states, void *stream) {

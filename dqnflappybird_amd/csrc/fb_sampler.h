@@ -46,6 +46,7 @@ __device__ __forceinline__ void set_sel(long long (&sel)[4], int i, int lane, lo
 __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k, long long setsize,
                                                     long long *__restrict__ out, uint32_t *mt, int *pool) {
     const int lane = threadIdx.x;
+    if (P.gate && lane == 0) fb_flag_store(&P.gate->c_entry, P.gate_val);      // (split schedule: whatever the caller's stream held before this launch is done)
     // the whole block is fetched beside the cursor (one round trip; a window that depends on the cursor would be two);
     // it is written back only when this call regenerated it -- otherwise the cursor alone
     for (int i = lane; i < 624; i += 64) mt[i] = P.mt->mt[i];
@@ -171,5 +172,13 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
     for (int q = 0; q < 4; q++) if (q * 64 + lane < k) out[q * 64 + lane] = sel[q];
     if (regenerated) for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];       // the block only changes when it is regenerated
     if (lane == 0) P.mt->idx = idx;
+    if (P.gate) {
+        // split schedule (fb_vec_step): a draw that holds none of the positions the env step beside it is still writing (the newest n_envs
+        // of the deque) lets the train trunk behind it start at once; otherwise that trunk waits for the env step
+        bool dirty = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dirty |= q * 64 + lane < k && sel[q] >= P.newest_from;
+        if (!__any(dirty) && lane == 0) { atomicAdd(&P.gate->clean_count, 1u); fb_flag_store(&P.gate->clean, P.gate_val); }
+    }
 }
 

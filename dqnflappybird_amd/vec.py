@@ -302,6 +302,12 @@ class QNet:
         L.check(L.lib().fb_qnet_overflow_count(self.h, int(bool(reset)), C.byref(v)), "fb_qnet_overflow_count")
         return v.value
 
+    def split_stats(self):
+        """(steps fb_vec_step issued with the train step on its own stream, how many of those started beside their env step)."""
+        a, b = C.c_int64(), C.c_int64()
+        L.check(L.lib().fb_qnet_split_stats(self.h, C.byref(a), C.byref(b)), "fb_qnet_split_stats")
+        return a.value, b.value
+
     def check_range(self):
         """raise FbError if a launch of this net met an activation beyond the fp32-equivalent path's range (its results are then
         inf / NaN / wrong where TensorFlow's fp32 would have carried on)"""

@@ -20,6 +20,25 @@
  *     (thread-local).  No C++ exception crosses the boundary;
  *   - one handle per GPU; handles are not thread-safe; distinct handles are
  *     independent.
+ *
+ * Environment variables libfbdqn.so reads (each ONCE, at the first call that consults it).  Every default is the product
+ * path; the other value selects a form the tests pin to the default bit for bit (an A/B or tuning switch, never a result):
+ *   FB_ACT_FUSED=0            acting forward as two launches (conv1, then conv2 + conv3) instead of the fused trunk
+ *   FB_VEC_HEAD_RIDER=0       fb_vec_step: head_kernel as its own launch instead of riding in the env launch
+ *   FB_VEC_SAMPLE_RIDER=0     fb_vec_step: random.sample as its own launch instead of riding in the env launch
+ *   FB_VEC_SPLIT=0            fb_vec_step keeps the train step on the caller's stream instead of a stream of its own beside acting + env
+ *   FB_ACT_SPW=5              five states per workgroup of the fused acting trunk also outside the split schedule (default 4)
+ *   FB_VEC_RING=0             fb_vec_step trains through fb_replay_gather + fb_qnet_train_step (u8 minibatch) instead of from the ring
+ *   FB_TRAIN_STEPS_GATHER=1   the same for fb_train_steps
+ *   FB_BW_MERGED=0            small-batch conv backward as two launches (conv_bx, conv_dw21) instead of conv_bw_kernel
+ *   FB_SPAN_SPLIT=p, FB_SPAN_BLOCKS=n   (two-launch form only) share / workgroup cap of W_fc1's Adam span in the first launch
+ *   FB_PER_STORE_AHEAD=0      Memory.store's tree update in line instead of on the memory's side stream (and with it the run-ahead sample)
+ *   FB_PER_SAMPLE_AHEAD=0     Memory.sample in line
+ *   FB_PER_UPDATE_AHEAD=0|1   Memory.batch_update in line / on the side stream whatever the env count (default: ahead from 4096 envs on)
+ *   FB_ENV_GRID_CAP=n, FB_ENV_GRID=n    env workgroups before they stride over envs
+ *   FB_ABORT_LOG=path         file the SIGABRT hook appends the native back-trace to (fb_debug_abort_backtrace)
+ * The Python side reads FB_LIB (another build of this library), FB_DP_NATIVE / FB_DP_OVERLAP (which data-parallel path, dist.py).
+ * Modes that DO change results (FB_PER_FAST, the train dtype, pipelined acting) are API calls below, never variables.
  */
 #ifndef FBDQN_H
 #define FBDQN_H
@@ -339,6 +358,15 @@ typedef struct {
      * reference does, BrainPrioritizedReplyDQN.py:147).  Any later call that touches the memory's tree joins that stream first. */
     double *isw; float *isw32; float *abs_err;
 } fb_step_buffers;
+/* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net, no flat_grad
+ * and a stream that is not being captured, fb_vec_step puts the train step on a stream of the net's own BESIDE the acting forward and
+ * the env step: both read the weights the previous step's Adam left, and the minibatch depends on the env step only when it holds one
+ * of the n_envs transitions this very step appends -- the draw decides that on the device and the chain then waits for the env step
+ * (hipStreamWaitValue64 on signal memory; ~3 % of the steps at 1024 envs / 1 M slots).  Results are those of the one-stream order bit
+ * for bit.  On return everything the step produced is ordered on `stream` (it waits for the chain), so callers need not know.
+ * FB_VEC_SPLIT=0 keeps the whole step on `stream`.
+ *   fb_qnet_split_stats -> [host] steps issued that way / how many of their minibatches started beside the env step (synchronous). */
+int fb_qnet_split_stats(fb_qnet_t net, int64_t *steps_host, int64_t *clean_host);
 int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo, int batch,
                 float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);
 

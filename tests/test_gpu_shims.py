@@ -289,6 +289,14 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
     assert (e1.get_state() == e2.get_state()).all()
     assert torch.equal(n1.store_params(), n2.store_params())
     assert torch.equal(nib1, nib2)
+    # the split schedule (train chain on the caller's stream beside acting + env on the net's side stream) ran where it applies, and
+    # BOTH of its cases did: minibatches that started beside their env step and ones that had to wait for it (a transition of the
+    # step itself was drawn); split_stats raises if any of the bounded waits between the chains gave up
+    issued, clean = n2.split_stats()
+    if N <= 1024:
+        assert issued == steps - 8 and 0 < clean < issued, (issued, clean)
+    else:
+        assert issued == 0                          # (the head cannot ride in the env launch there: one stream)
     # the ring the riders filled holds what the push kernel stores: oldest, newest and a stride of positions in between
     assert len(r1) == len(r2)
     probe = torch.cat([torch.arange(0, 48), torch.arange(100, len(r1) - 48, 331), torch.arange(len(r1) - 48, len(r1))]).cuda()
