@@ -36,6 +36,17 @@ static inline hipStream_t fb_stream(void *s) { return reinterpret_cast<hipStream
 __device__ __forceinline__ unsigned long long fb_flag_load(const unsigned long long *flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_flag_store(unsigned long long *flag, unsigned long long v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_flag_acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+// A launch's GATE workgroup: one extra workgroup at the end of the grid whose first thread does nothing but wait for a word -- so the
+// launch does not retire, and the next launch on its stream does not start, before the other stream's kernel has.  One wave spins; the
+// kernels behind the gate never do (waves that spin must not hold what the kernels they wait for need: a launch whose every workgroup
+// waited for the acting trunk to retire kept that trunk, which wants whole SIMDs, from ever being placed).
+struct FbGate { const unsigned long long *flag; unsigned long long val; unsigned *timeouts; };      // flag == NULL: no gate workgroup in the grid
+__device__ __forceinline__ void fb_flag_wait(const unsigned long long *flag, unsigned long long v, unsigned *timeouts);
+__device__ __forceinline__ bool fb_gate_workgroup(const FbGate &g) {          // true: this workgroup was the gate (it has waited; return)
+    if (!g.flag || blockIdx.x != gridDim.x - 1) return false;
+    if (threadIdx.x == 0) fb_flag_wait(g.flag, g.val, g.timeouts);
+    return true;
+}
 __device__ __forceinline__ void fb_flag_wait(const unsigned long long *flag, unsigned long long v, unsigned *timeouts) {
     if (fb_flag_load(flag) >= v) return;
     const long long t0 = wall_clock64();
@@ -76,8 +87,8 @@ struct FbMT { uint32_t mt[624]; uint32_t idx; };
 
 // what a draw needs: the generator, the population size n = len(memory) at the time of the call, an error flag
 // gate (split schedule of fb_vec_step, or NULL): the draw is that step's first launch on the caller's stream (it stores c_entry = gate_val
-// on arrival), and when none of the drawn positions is >= newest_from -- the minibatch touches nothing the env step running beside the
-// draw is still writing -- it stores clean = gate_val
+// on arrival) and the gate of the train chain behind it: it does not retire before the env step its minibatch depends on has (the
+// previous step's when none of the drawn positions is >= newest_from, else this step's own)
 struct FbSplitFlags;
 struct FbSampleCtx { FbMT *mt; int *error; long long n; FbSplitFlags *gate; unsigned long long gate_val; long long newest_from; };
 // random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
@@ -114,17 +125,24 @@ int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *r
 // holds one of the transitions this very step appends (the sampler decides that on the device and opens `gate` itself when it does not).
 struct FbSplitFlags {                          // [dev], one word per 64 bytes; each holds the number of the last step that reached the point
     unsigned long long c_entry, p0[7];         // the caller's stream has reached this step's first launch (the draw): all it held before is done
-    unsigned long long clean, p1[7];           // the draw of this step holds none of the transitions the step appends
     unsigned long long trunk_done, p2[7];      // the acting trunk has retired (stored by the fc1 launch behind it)
     unsigned long long fc1_done, p3[7];        // the acting forward's fc1 launch has retired
     unsigned long long env_done, p4[7];        // the env step (with the push and the head riding in it) has retired
-    unsigned clean_count, timeouts;            // minibatches that started beside their env step; waits that gave up (must stay 0)
+    unsigned clean_count;                      // minibatches that started beside their env step
+    unsigned timeouts[7];                      // waits that gave up (must stay 0), per site: 0 the draw (env_done) 1 the side stream's entry (c_entry) 2 the fc1 backward launch's gate (trunk_done) 3 the conv backward launch's gate (fc1_done) 4 the Adam launch's last wait (env_done)
+    unsigned long long probe_a, p6[7], probe_b, p7[7];      // fb_split_probe's hand-shake words
+    unsigned probe_fail;
 };
 struct FbSplitCtx {
     hipStream_t tstream;                       // the side stream: acting forward + env step (the train chain stays on the caller's stream)
     FbSplitFlags *f;
     unsigned long long seq;                    // steps issued so far
+    // HIP multiplexes streams onto a few hardware queues and promises no concurrency between two streams: on a shared queue a kernel
+    // that waits for a word a LATER launch stores would sit in front of it until its time-out.  So the pair (side stream, caller's
+    // stream) shakes hands once, both ways, with 20 ms waits, before the schedule is used with it (fb_split_probe)
+    const void *probed_stream; int probed_ok; unsigned long long probe_seq;
 };
+int fb_split_probe(FbSplitCtx *ctx, void *stream);      // 1: the side stream and `stream` make progress independently of each other (synchronises both, once per stream)
 FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h);    // created on first use; NULL when the runtime lacks stream memory operations (the caller falls back)
 // random.sample(range(n after the coming push), batch) -> idx on `stream`, opening ctx->gate at ctx->seq when the draw is clean; 1 when launched
 int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream);

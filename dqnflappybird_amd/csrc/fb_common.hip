@@ -167,12 +167,13 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // -> it waits for the fc1 launch; workspaces -> the fused acting forward has its own (hf_act / hp_act); the acting forward against
     // the previous step's Adam, and against whatever else the caller's stream held at entry -> ev_entry.
     static const bool split_on = !(getenv("FB_VEC_SPLIT") && atoi(getenv("FB_VEC_SPLIT")) == 0);      // A/B knob: 0 = one stream
-    if (split_on && train && !per && !b->flat_grad && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
+    if (split_on && train && !per && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
         hipStream_t A = reinterpret_cast<hipStream_t>(stream);       // (not fb_stream(): the light-entry test below compares fb_api_epoch with its value at the last exit)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(A, &cap);
         FbSampleRider probe;
         FbSplitCtx *sc = cap == hipStreamCaptureStatusNone && fb_replay_sample_rider(replay, batch, b->idx, &probe) ? fb_qnet_split_ctx(net) : nullptr;
+        if (sc && !fb_split_probe(sc, stream)) sc = nullptr;      // (the two streams share a hardware queue: one stream, as before)
         if (sc) {
             // Which chain goes where: the TRAIN chain stays on the caller's stream -- it is the longer one, step k + 1's follows step k's
             // in stream order with no hop, and whatever the caller puts on `stream` between calls (a target sync, reads of idx / loss) is
@@ -183,9 +184,10 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             //   S's first launch is one wave waiting for c_entry: the draw -- this call's first launch on `stream` -- has started, so the
             //     previous Adam and everything else the caller's stream held are done (its reads of the previous step's rewards included);
             //   the acting forward's fc1 launch stores trunk_done, a one-thread launch behind it fc1_done, one behind the env launch env_done;
-            //   the train trunk waits for env_done (of the previous step: nothing else orders `stream` behind that push; of this step
-            //     when the draw was not clean), the Adam span's stores for trunk_done, the Adam launch's stores for fc1_done, and the
-            //     Adam launch does not retire before env_done: on return every result of the step is ordered on `stream` as before.
+            //   the draw does not retire before env_done (of the previous step: nothing else orders `stream` behind that push; of this step
+            //     when the draw was not clean) -- one wave, so that nothing that spins holds what the kernels it waits for need --, the
+            //     Adam span's stores wait for trunk_done, the Adam launch's stores for fc1_done, and the Adam launch does not retire
+            //     before env_done: on return every result of the step is ordered on `stream` as before.
             hipStream_t C = A, S = sc->tstream;
             FbSplitFlags *F = sc->f;
             sc->seq += 1;
@@ -200,7 +202,9 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             fb_replay_begin_push_rider(replay, &prider);       // (counts the push: the minibatch below is addressed in the memory as it will be)
             FbRingSrc ring;
             rc = fb_replay_ring_src(replay, batch, b->idx, b->a, b->r, b->t, &ring);
-            if (rc == FB_OK) rc = fb_qnet_train_step_ring(net, algo, batch, &ring, nullptr, gamma, b->loss, nullptr, nullptr, C, nullptr, sc);
+            // (flat_grad: the data-parallel step -- the gradient is exported, and the fb_qnet_apply_adam / fb_dist_reduce_apply that completes
+            // the step takes the Adam launch's place in the hand-over: until then `stream` is NOT yet ordered behind this step's env launch)
+            if (rc == FB_OK) rc = fb_qnet_train_step_ring(net, algo, batch, &ring, nullptr, gamma, b->loss, nullptr, b->flat_grad, C, nullptr, sc);
             const int rc2 = fb_env_step_rider(env, b->actions, nullptr, b->frame_bits, b->reward, b->terminal, b->score, nullptr, &prider, &hrider, S);
             const int rc3 = fb_split_set(sc, &F->env_done, sc->seq, S);
             return rc != FB_OK ? rc : rc2 != FB_OK ? rc2 : rc3;

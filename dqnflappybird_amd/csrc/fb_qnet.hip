@@ -891,7 +891,6 @@ struct C23T {
     FbRingSrc ring; float *p1o; uint8_t *amax; unsigned long long *ring_fo;
     uint16_t *a3s; size_t pl3;               // conv3's output as planes too ([plane][row * 25 + pixel][64]) when fc1_sp_kernel follows, or NULL
     unsigned *ovf;                           // the net's overflow word (note_overflow)
-    FbSplitFlags *gate; unsigned long long gate_val;      // split schedule (or NULL): nothing of the ring is read before the env steps it may depend on have retired
 };
 
 // RING = true: conv1 of the state in front of conv2 + conv3, fed from the replay's 1-bit frame ring.  The workgroup locates its
@@ -958,13 +957,6 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         const uint4 wc0 = w1g[t5], wc1 = w1g[t5 + 512], wc2 = w1g[t5 + 1024], wc3 = w1g[t5 + 1536];
         // ---- where the state lives: frames tt - 3 + fshift .. of env e (four threads, one frame offset each)
         if (tid < 4) {
-            // split schedule: the minibatch may hold a transition the env step running beside this launch is still appending -- the draw
-            // opened the gate if it does not, the env step's stream opens it otherwise (every other thread meets these four at the barrier)
-            // (the previous step's env launch in any case: nothing else orders this stream behind it)
-            if (a.gate) {
-                fb_flag_wait(&a.gate->env_done, fb_flag_load(&a.gate->clean) == a.gate_val ? a.gate_val - 1 : a.gate_val, &a.gate->timeouts);
-                fb_flag_acquire();
-            }
             long long tt; int e;
             fb_ring_locate(a.ring.c, a.ring.steps, a.ring.idx[blockIdx.x], tid == 0 && blockIdx.y == 0, tt, e);
             const unsigned long long o = fb_frame_off(a.ring.c, tt - 3 + s.fshift + tid, e);
@@ -1591,6 +1583,7 @@ struct Bw1Args {
     double gamma;
     float *grad, *dh3, *loss, *abs_err, *y_out;
     AdamDev *adam; int tick;
+    FbGate gate;                             // split schedule: the launch does not retire before the acting trunk on the other stream has (fb_gate_workgroup)
 };
 constexpr int BW_DX_ROW = 4;                 // + floats of padding per dhf row in LDS (dX role): conflict-free ds_read_b128
 constexpr int BW_DW_ROW = 36;                // dhf row stride in LDS (dW role)
@@ -1941,6 +1934,7 @@ constexpr int BW_LDS = BW_LDS_COMMON + (BW_LDS_DX > BW_LDS_DW ? BW_LDS_DX : BW_L
 
 __global__ __launch_bounds__(512) void fc1_bwd2_kernel(Bw1Args L) {
     __shared__ float smem_bw[BW_LDS];
+    if (fb_gate_workgroup(L.gate)) return;
     const bool dx = (int)blockIdx.x < L.n_dx;
     if (L.A == 2) { if (dx) fc1_bwd2_body<2, true>(L, smem_bw); else fc1_bwd2_body<2, false>(L, smem_bw); }
     else { if (dx) fc1_bwd2_body<MAXA, true>(L, smem_bw); else fc1_bwd2_body<MAXA, false>(L, smem_bw); }
@@ -2326,16 +2320,12 @@ __device__ __forceinline__ void adam4(float4 &P, float4 &Mv, float4 &V, const fl
 // that follow (conv3 / conv2 / conv1 backward) neither read W_fc1 nor fill more than ~200 of the 256 CUs, and wait on
 // latency rather than on HBM.  Its Adam update therefore rides as extra workgroups at the END of the conv3 backward
 // launch (float4 range [q0, q1) of the flat parameter vector); adam_fused_kernel at the end of the step skips that range.
-// wait_flag (split schedule, or NULL): nothing is STORED before *wait_flag >= wait_val -- the acting trunk running beside this launch on
-// another stream re-splits W_fc1's planes from these very parameters in its first microseconds (the loads do not wait)
-struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; const unsigned long long *wait_flag; unsigned long long wait_val; unsigned *timeouts; };
+struct AdamSpan { float *p, *m, *v; const float *g; const AdamDev *ad; int q0, q1; };
 __device__ __forceinline__ void adam_span_body(int blk, int nblk, const AdamSpan a) {
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
-    bool open = !a.wait_flag || fb_flag_load(a.wait_flag) >= a.wait_val;
     for (int q = a.q0 + blk * (int)blockDim.x + (int)threadIdx.x; q < a.q1; q += nblk * (int)blockDim.x) {
         float4 P = reinterpret_cast<float4 *>(a.p)[q], Mv = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
         adam4(P, Mv, V, reinterpret_cast<const float4 *>(a.g)[q], alpha, omb1, omb2, eps);
-        if (!open) { fb_flag_wait(a.wait_flag, a.wait_val, a.timeouts); open = true; }
         reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
     }
 }
@@ -2521,7 +2511,8 @@ template <int NSP, bool RING>
 __global__ __launch_bounds__(512) void conv_dw21_kernel(int nz, int B, const float *__restrict__ p1, const float *__restrict__ dh2,
                                                         const uint8_t *__restrict__ states, const float *__restrict__ dp1,
                                                         const uint8_t *__restrict__ amax, float *__restrict__ slabs, size_t slab_stride,
-                                                        float *__restrict__ slabs1, size_t stride1, int rb, Dw1Ring ring, int n_adam, AdamSpan span) {
+                                                        float *__restrict__ slabs1, size_t stride1, int rb, Dw1Ring ring, int n_adam, AdamSpan span, FbGate gate) {
+    if (fb_gate_workgroup(gate)) return;
     const int n2 = 34 * nz;                       // (slabs1 / stride1: where conv1's slabs go -- the common slab set, or the fold buffer)
     __shared__ uint4 pool[Dw1Lds<NSP>::U4];
     static_assert(Dw1Lds<NSP>::U4 >= 2048, "the conv2 tiles borrow the pool");
@@ -2742,8 +2733,9 @@ __device__ __forceinline__ void bw1_main(int blk, int part, const Bw1Pre &pre, c
 template <int NS, bool RING>
 __global__ __launch_bounds__(512) void conv_bw_kernel(BxArgs bx, int B, float *__restrict__ slabs, size_t slab_stride, float *__restrict__ slabs1,
                                                       size_t stride1, const uint8_t *__restrict__ states, const uint8_t *__restrict__ amax, Dw1Ring ring,
-                                                      int n_adam, AdamSpan span, FbSampleRider rider, int rb) {
+                                                      int n_adam, AdamSpan span, FbSampleRider rider, int rb, FbGate gate) {
     __shared__ uint4 pool[BwLds<NS>::U4];
+    if (fb_gate_workgroup(gate)) return;
     static_assert(BwLds<NS>::U4 * 16 >= FB_SAMPLE_LDS_WORDS * 4, "the sampler rider borrows the pool");
     uint4 *aux = pool + BwLds<NS>::CH;
     float *dp1s = reinterpret_cast<float *>(aux + BW_AUX_U4);
@@ -3043,14 +3035,11 @@ struct AdamFused {
     int tail0;                       // first float4 behind W_fc1
     int n_rest;                      // workgroups of the third role
     int lanes;                       // lanes per float4 in the third role: 4 (slab mode: a chunk each) or 1
-    // split schedule (or NULL): nothing is STORED before the acting forward's fc1 launch on the other stream has retired (it reads the conv
-    // planes and biases, records the version word and copies the head's parameters); and the launch does not retire before that
-    // stream's env step has (whatever the caller puts on this stream next may read the env step's outputs)
+    // split schedule (or NULL): the launch does not retire before the other stream's env step has (whatever the caller puts on this stream
+    // next may read the env step's outputs).  (That stream's fc1 launch -- which reads the conv planes and biases this launch rewrites,
+    // records the version word and copies the head's parameters -- has retired: the conv backward launch's gate workgroup waited for it.)
     FbSplitFlags *split; unsigned long long split_val;
 };
-__device__ __forceinline__ void adam_store_gate(const AdamFused &a, bool &open) {
-    if (!open) { fb_flag_wait(&a.split->fc1_done, a.split_val, &a.split->timeouts); open = true; }
-}
 __device__ __forceinline__ float4 shfl4(float4 v, int src) { return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src)); }
 __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRider gr) {
     __shared__ float tile[8][68];
@@ -3062,7 +3051,6 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     }
     const float alpha = a.ad->alpha, omb1 = 1.f - a.ad->b1, omb2 = 1.f - a.ad->b2, eps = a.ad->eps;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool open = !a.split || fb_flag_load(&a.split->fc1_done) >= a.split_val;
     if (bid < ADAMF_T2 + ADAMF_T3) {
         const bool l3 = bid >= ADAMF_T2;
         const int k0 = 8 * (l3 ? bid - ADAMF_T2 : bid), woff = l3 ? OFF_W3 : OFF_W2, CI = l3 ? 64 : 32, z = l3 ? a.z3 : a.z2;
@@ -3078,7 +3066,6 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
             Gv = c == 0 ? slab_combine4(ca, oa, cb, ob) : slab_combine4(oa, ca, ob, cb);
         } else Gv = reinterpret_cast<const float4 *>(a.g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
-        adam_store_gate(a, open);
         if (c == 0) {
             reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
             *reinterpret_cast<float4 *>(&tile[kr][4 * c4]) = P;
@@ -3119,7 +3106,6 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
             Gv = z > 0 ? slab_combine4(c0, c1, c2, c3) : reinterpret_cast<const float4 *>(a.g)[q];
         } else Gv = z > 0 ? slab_sum4(a.slabs, a.slab_stride, q, z) : reinterpret_cast<const float4 *>(a.g)[q];
         adam4(P, Mv, V, Gv, alpha, omb1, omb2, eps);
-        adam_store_gate(a, open);
         if (live && c == 0) {
             reinterpret_cast<float4 *>(a.p)[q] = P; reinterpret_cast<float4 *>(a.m)[q] = Mv; reinterpret_cast<float4 *>(a.v)[q] = V;
             if (q * 4 < OFF_B1) {                                        // W_conv1 changed: refresh its two fp16 planes
@@ -3130,7 +3116,6 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
     }
     // the update consumes the pending tick and makes a new parameter version, of which the conv planes are current (nothing in this
     // launch reads these words)
-    adam_store_gate(a, open);
     if (bid == ADAMF_T2 + ADAMF_T3 && tid == 0) { a.ad->applies = a.ad->ticks; a.ad->pver[0] += 1; a.ad->wverc[0] = a.ad->pver[0]; }
     if (bid == ADAMF_T2 + ADAMF_T3 && tid < (int)(a.n & 3)) {
         const long long q = (n4 << 2) + tid;
@@ -3139,7 +3124,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(AdamFused a, FbGatherRi
         a.p[q] -= (mm * alpha) / (sqrtf(vv) + eps);
         a.m[q] = mm; a.v[q] = vv;
     }
-    if (a.split && bid == ADAMF_T2 + ADAMF_T3 && tid == 0) fb_flag_wait(&a.split->env_done, a.split_val, &a.split->timeouts);
+    if (a.split && bid == ADAMF_T2 + ADAMF_T3 && tid == 0) fb_flag_wait(&a.split->env_done, a.split_val, &a.split->timeouts[4]);
 }
 
 // tf.truncated_normal(stddev=0.01) weights, 0.01 biases (BrainDQN.py:123-152)
@@ -3196,6 +3181,7 @@ struct fb_qnet {
     // start its Adam launch as soon as that fc1 launch is through
     float *hf_act, *hp_act;
     FbSplitCtx *split;               // fb_qnet_split_ctx
+    bool split_adam_pending;         // a split step exported its gradient: the fb_qnet_apply_adam that completes it takes over the Adam launch's waits
 };
 
 static NetOff make_off(int FC, int A, int dueling) {
@@ -3290,8 +3276,54 @@ FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h) {
     return c;
 }
 
+// one wave that waits up to 20 ms for *flag >= v and counts a failure otherwise
+__global__ void probe_wait_kernel(const unsigned long long *flag, unsigned long long v, unsigned *fail) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (fb_flag_load(flag) < v) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 2000000LL) { atomicAdd(fail, 1u); break; }
+    }
+}
+
+static bool probe_once(FbSplitCtx *c, hipStream_t S, hipStream_t C) {
+    FbSplitFlags *F = c->f;
+    const unsigned long long v = ++c->probe_seq;
+    unsigned before = 0, after = 0;
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
+    if (hipMemcpy(&before, &F->probe_fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    // the waiter is launched FIRST each time: on a shared queue it sits in front of the launch that would release it
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, S, (const unsigned long long *)&F->probe_a, v, &F->probe_fail);
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, C, &F->probe_a, v);
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, C, (const unsigned long long *)&F->probe_b, v, &F->probe_fail);
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, S, &F->probe_b, v);
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
+    if (hipMemcpy(&after, &F->probe_fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return after == before;
+}
+
+int fb_split_probe(FbSplitCtx *c, void *stream) {
+    if (!c || !c->tstream) return 0;
+    if (c->probed_stream == stream && c->seq > 0) return c->probed_ok;
+    hipStream_t C = reinterpret_cast<hipStream_t>(stream);
+    bool ok = probe_once(c, c->tstream, C);
+    // a side stream that landed on the caller's queue: a few more tries with fresh streams (the runtime deals queues out in turn)
+    for (int attempt = 0; !ok && attempt < 6; attempt++) {
+        hipStream_t ts = nullptr;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&ts, hipStreamNonBlocking, attempt & 1 ? (lo + hi) / 2 : lo) != hipSuccess) break;
+        (void)hipStreamSynchronize(c->tstream); (void)hipStreamDestroy(c->tstream);
+        c->tstream = ts;
+        ok = probe_once(c, ts, C);
+    }
+    (void)hipGetLastError();
+    c->probed_stream = stream; c->probed_ok = ok ? 1 : 0;
+    return c->probed_ok;
+}
+
 int fb_split_wait(const FbSplitCtx *c, const unsigned long long *flag, unsigned long long v, void *stream) {
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, fb_stream(stream), flag, v, &c->f->timeouts);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, fb_stream(stream), flag, v, &c->f->timeouts[1]);
     FB_LAUNCH_CHECK();
     return FB_OK;
 }
@@ -3307,9 +3339,10 @@ extern "C" int fb_qnet_split_stats(fb_qnet_t h, int64_t *steps_host, int64_t *cl
     *steps_host = 0; *clean_host = 0;
     if (!h->split || !h->split->tstream) return FB_OK;
     FB_CHECK_HIP(hipDeviceSynchronize());
-    unsigned v[2] = {0, 0};
+    unsigned v[8] = {0};
     FB_CHECK_HIP(hipMemcpy(v, &h->split->f->clean_count, sizeof(v), hipMemcpyDeviceToHost));
-    FB_REQUIRE(v[1] == 0, "fb_qnet_split_stats: %u wait(s) between the two chains of the split schedule gave up after 0.2 s: the results of those steps are not to be trusted", v[1]);
+    FB_REQUIRE(!(v[1] | v[2] | v[3] | v[4] | v[5]), "fb_qnet_split_stats: waits between the two chains of the split schedule gave up after 0.2 s (the draw %u, the side stream's entry %u, "
+               "the Adam span %u, the Adam launch's stores %u, its last wait %u): the results of those steps are not to be trusted", v[1], v[2], v[3], v[4], v[5]);
     *steps_host = (int64_t)h->split->seq; *clean_host = (int64_t)v[0];
     return FB_OK;
 }
@@ -3483,7 +3516,6 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
     if (trunk) FB_K(K_CONV2) {                       // conv1 + pool + conv2 + conv3 of every state in ONE launch
         if (sp) { c23t.a3s = h->a3s; c23t.pl3 = pl2; }      // >= 256 states per slice: fc1_sp_kernel follows and reads conv3's output as planes
         c23t.ring = *p.ring; c23t.p1o = h->p1; c23t.amax = h->amax; c23t.ring_fo = h->ring_fo;
-        if (p.train && p.split && only < 0) { c23t.gate = p.split->f; c23t.gate_val = p.split->seq; }
         const bool w16 = maxc * p.ns <= 256;          // at most one workgroup per CU anyway: spend the idle SIMD slots on conv1's second round
         if (nsp == 3 && w16) hipLaunchKernelGGL((conv23_t_kernel<3, true, true>), dim3(maxc, p.ns), dim3(1024), 0, st, c23t);
         else if (nsp == 3) hipLaunchKernelGGL((conv23_t_kernel<3, true>), dim3(maxc, p.ns), dim3(512), 0, st, c23t);
@@ -3612,7 +3644,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             L.grad = G; L.dh3 = h->dh3; L.loss = p.loss; L.abs_err = p.abs_err; L.y_out = p.y;
             if (p.tick) h->adam_ticked = !p.apply_adam;              // stays pending until fb_qnet_apply_adam consumes it
             L.adam = h->adam; L.tick = p.tick; L.rb = rbt;
-            hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7), dim3(512), 0, st, L);
+            L.gate = FbGate{nullptr, 0, nullptr};
+            if (p.split && only < 0) L.gate = FbGate{&p.split->f->trunk_done, p.split->seq, &p.split->f->timeouts[2]};
+            hipLaunchKernelGGL(fc1_bwd2_kernel, dim3(ndx1 + (FC / 32) * 7 + (L.gate.flag ? 1 : 0)), dim3(512), 0, st, L);
         } } else FB_K(K_FC1_BWD) {
             const int ndx = ((B + 31) / 32) * 50, ntile = ndx + 50 * (FC / 32);        // one workgroup per 32 x 32 tile, data-gradient tiles first
             const dim3 gb(ntile);
@@ -3638,12 +3672,12 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         // is the latency-bound chains beside it, wherever it rides -- so the default stays "all of it beside the data-gradient chain")
         static const int span_pct = getenv("FB_SPAN_SPLIT") ? atoi(getenv("FB_SPAN_SPLIT")) : 100;     // tuning knob: per cent of the span in the first launch
         const int spanm = span0 + (int)(((long long)(span1 - span0) * span_pct / 100) & ~511LL);
-        // (split schedule: the span's stores wait for the acting trunk on the other stream, wherever the span rides)
-        const unsigned long long *swf = p.split && only < 0 ? &p.split->f->trunk_done : nullptr;
-        const unsigned long long swv = p.split ? p.split->seq : 0;
-        unsigned *swt = p.split ? &p.split->f->timeouts : nullptr;
-        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, spanm, swf, swv, swt};
-        const AdamSpan span_b{h->params[0], h->adam_m, h->adam_v, G, h->adam, spanm, span1, swf, swv, swt};
+        const AdamSpan span{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, spanm};
+        const AdamSpan span_b{h->params[0], h->adam_m, h->adam_v, G, h->adam, spanm, span1};
+        // split schedule: the fc1 backward launch has waited for the acting trunk on the other stream (its gate workgroup), so W_fc1's Adam
+        // span may ride in the launches below; the last of them waits for that stream's fc1 launch, so the Adam launch may follow
+        FbGate gate_fc1{nullptr, 0, nullptr};
+        if (p.split && only < 0) gate_fc1 = FbGate{&p.split->f->fc1_done, p.split->seq, &p.split->f->timeouts[3]};
         FbSampleRider srider;
         memset(&srider, 0, sizeof(srider));
         if (p.sample_rider) srider = *p.sample_rider;
@@ -3673,15 +3707,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                     const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
                     float *s1 = fold1 ? h->slabs1 : h->slabs;
                     const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
-                    const dim3 g(BW_WGS * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0));
-                    const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1, swf, swv, swt};
+                    const dim3 g(BW_WGS * B + n_adam5 + n_adam5b + (srider.k ? 1 : 0) + (gate_fc1.flag ? 1 : 0));
+                    const AdamSpan span_all{h->params[0], h->adam_m, h->adam_v, G, h->adam, span0, span1};
                     const int n_ad = n_adam5 + n_adam5b;
                     if (h->nsplit_train == 3) {
-                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<3, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
-                        else hipLaunchKernelGGL((conv_bw_kernel<3, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<3, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt, gate_fc1);
+                        else hipLaunchKernelGGL((conv_bw_kernel<3, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt, gate_fc1);
                     } else {
-                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<1, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
-                        else hipLaunchKernelGGL((conv_bw_kernel<1, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt);
+                        if (p.ring) hipLaunchKernelGGL((conv_bw_kernel<1, true>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt, gate_fc1);
+                        else hipLaunchKernelGGL((conv_bw_kernel<1, false>), g, dim3(512), 0, st, bx, B, h->slabs, ss, s1, st1, p.s, (const uint8_t *)h->amax, dr, n_ad, span_all, srider, rbt, gate_fc1);
                     }
                 }
                 if (fold1) FB_K(K_CONV2_BWD) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
@@ -3703,14 +3737,15 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 const Dw1Ring dr{p.ring ? p.ring->c.bits : nullptr, h->ring_fo};
                 float *s1 = fold1 ? h->slabs1 : h->slabs;
                 const size_t st1 = fold1 ? (size_t)CONV1_PARAMS : ss;
-                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * zt2 + 2 * B + n_adam5b), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b);
-                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B + n_adam5b), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b);
+                if (p.ring) hipLaunchKernelGGL((conv_dw21_kernel<2, true>), dim3(34 * zt2 + 2 * B + n_adam5b + (gate_fc1.flag ? 1 : 0)), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b, gate_fc1);
+                else hipLaunchKernelGGL((conv_dw21_kernel<2, false>), dim3(34 * zt2 + 2 * B + n_adam5b + (gate_fc1.flag ? 1 : 0)), dim3(512), 0, st, zt2, B, h->p1, h->dh2, p.s, h->dp1, h->amax, h->slabs, ss, s1, st1, rbt, dr, n_adam5b, span_b, gate_fc1);
                 if (fold1) hipLaunchKernelGGL(slab_fold_kernel, dim3((CONV1_PARAMS + 255) / 256, z1), dim3(256), 0, st, h->slabs1, 2 * B, fold, h->slabs, ss);
             }
             }
         }
         // data-parallel path: the caller needs the complete flat gradient; fused path: Adam sums the slabs itself
         const int z2 = z3;
+        if (p.split && only < 0) h->split_adam_pending = !p.apply_adam;
         if (!p.apply_adam) FB_K(K_SLAB) hipLaunchKernelGGL(slab_reduce_kernel, dim3((CONV_PARAMS / 4 + 255) / 256), dim3(256), 0, st, h->slabs, ss, z1, z2, z3, G);
         // split schedule: the Adam launch rewrites the conv planes / biases the acting trunk reads and the parameters its fc1 launch copies for the head
 
@@ -3814,7 +3849,9 @@ extern "C" int fb_qnet_apply_adam(fb_qnet_t h, const float *flat_grad, void *str
     af.slabs = nullptr; af.slab_stride = 0; af.z1 = af.z2 = af.z3 = 0;
     af.w1s = h->w1s[0]; af.wsp = h->wsp[0]; af.FC = h->FC; af.tail0 = OFF_WF1 / 4;
     af.n_rest = ADAM_GRID; af.lanes = 1;
-    af.split = nullptr; af.split_val = 0;
+    // (the update that completes a split step: its stores wait for that step's acting forward, and it does not retire before that step's env launch)
+    af.split = h->split_adam_pending && h->split && h->split->tstream ? h->split->f : nullptr; af.split_val = af.split ? h->split->seq : 0;
+    h->split_adam_pending = false;
     hipLaunchKernelGGL(adam_fused_kernel, dim3(ADAMF_T2 + ADAMF_T3 + af.n_rest), dim3(256), 0, st, af, FbGatherRider{});
     FB_LAUNCH_CHECK();
     return FB_OK;

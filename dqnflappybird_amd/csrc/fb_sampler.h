@@ -173,12 +173,18 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
     if (regenerated) for (int i = lane; i < 624; i += 64) P.mt->mt[i] = mt[i];       // the block only changes when it is regenerated
     if (lane == 0) P.mt->idx = idx;
     if (P.gate) {
-        // split schedule (fb_vec_step): a draw that holds none of the positions the env step beside it is still writing (the newest n_envs
-        // of the deque) lets the train trunk behind it start at once; otherwise that trunk waits for the env step
+        // split schedule (fb_vec_step): this launch is the gate of the train chain behind it.  A draw that holds none of the positions the
+        // env step beside it is still writing (the newest n_envs of the deque) lets the chain start at once -- once the PREVIOUS step's
+        // env launch has retired, which nothing else orders this stream behind; otherwise it waits for this step's.  The wait sits here,
+        // in a launch of one wave, and not in the trunk behind it: waves that spin must not hold what the kernels they wait for need.
         bool dirty = false;
 #pragma unroll
         for (int q = 0; q < 4; q++) dirty |= q * 64 + lane < k && sel[q] >= P.newest_from;
-        if (!__any(dirty) && lane == 0) { atomicAdd(&P.gate->clean_count, 1u); fb_flag_store(&P.gate->clean, P.gate_val); }
+        dirty = __any(dirty);
+        if (lane == 0) {
+            if (!dirty) atomicAdd(&P.gate->clean_count, 1u);
+            fb_flag_wait(&P.gate->env_done, dirty ? P.gate_val : P.gate_val - 1, &P.gate->timeouts[0]);
+        }
     }
 }
 

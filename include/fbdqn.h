@@ -26,7 +26,7 @@
  *   FB_ACT_FUSED=0            acting forward as two launches (conv1, then conv2 + conv3) instead of the fused trunk
  *   FB_VEC_HEAD_RIDER=0       fb_vec_step: head_kernel as its own launch instead of riding in the env launch
  *   FB_VEC_SAMPLE_RIDER=0     fb_vec_step: random.sample as its own launch instead of riding in the env launch
- *   FB_VEC_SPLIT=0            fb_vec_step keeps the train step on the caller's stream instead of a stream of its own beside acting + env
+ *   FB_VEC_SPLIT=0            fb_vec_step keeps acting + env on the caller's stream in front of the train step instead of beside it on a second stream
  *   FB_ACT_SPW=5              five states per workgroup of the fused acting trunk also outside the split schedule (default 4)
  *   FB_VEC_RING=0             fb_vec_step trains through fb_replay_gather + fb_qnet_train_step (u8 minibatch) instead of from the ring
  *   FB_TRAIN_STEPS_GATHER=1   the same for fb_train_steps
@@ -358,12 +358,15 @@ typedef struct {
      * reference does, BrainPrioritizedReplyDQN.py:147).  Any later call that touches the memory's tree joins that stream first. */
     double *isw; float *isw32; float *abs_err;
 } fb_step_buffers;
-/* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net, no flat_grad
- * and a stream that is not being captured, fb_vec_step puts the train step on a stream of the net's own BESIDE the acting forward and
- * the env step: both read the weights the previous step's Adam left, and the minibatch depends on the env step only when it holds one
+/* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net
+ * and a stream that is not being captured, fb_vec_step keeps the train step on `stream` and puts the acting forward and the env step
+ * on a stream of the net's own BESIDE it: both read the weights the previous step's Adam left, and the minibatch depends on the env step only when it holds one
  * of the n_envs transitions this very step appends -- the draw decides that on the device and the chain then waits for the env step
- * (hipStreamWaitValue64 on signal memory; ~3 % of the steps at 1024 envs / 1 M slots).  Results are those of the one-stream order bit
- * for bit.  On return everything the step produced is ordered on `stream` (it waits for the chain), so callers need not know.
+ * (the chains hand over through device words that kernels store and poll -- every wait bounded at 0.2 s and counted; ~3 % of the steps
+ * wait at 1024 envs / 1 M slots).  Results are those of the one-stream order bit
+ * for bit.  On return everything the step produced is ordered on `stream`, so callers need not know -- with one exception: a step that
+ * exports its gradient (flat_grad) is completed by fb_qnet_apply_adam / fb_dist_reduce_apply on the same stream, and only behind THAT call
+ * is `stream` ordered behind the step's env launch (actions, rewards, terminals, scores, frame bits).
  * FB_VEC_SPLIT=0 keeps the whole step on `stream`.
  *   fb_qnet_split_stats -> [host] steps issued that way / how many of their minibatches started beside the env step (synchronous). */
 int fb_qnet_split_stats(fb_qnet_t net, int64_t *steps_host, int64_t *clean_host);

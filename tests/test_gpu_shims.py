@@ -293,10 +293,9 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
     # BOTH of its cases did: minibatches that started beside their env step and ones that had to wait for it (a transition of the
     # step itself was drawn); split_stats raises if any of the bounded waits between the chains gave up
     issued, clean = n2.split_stats()
+    assert issued == steps - 8
     if N <= 1024:
-        assert issued == steps - 8 and 0 < clean < issued, (issued, clean)
-    else:
-        assert issued == 0                          # (the head cannot ride in the env launch there: one stream)
+        assert 0 < clean < issued, (issued, clean)  # (2304 envs in a 20 000-slot memory: a clean draw is a 2 % event)
     # the ring the riders filled holds what the push kernel stores: oldest, newest and a stride of positions in between
     assert len(r1) == len(r2)
     probe = torch.cat([torch.arange(0, 48), torch.arange(100, len(r1) - 48, 331), torch.arange(len(r1) - 48, len(r1))]).cuda()
@@ -593,7 +592,7 @@ def test_native_dp_step_equals_the_plain_data_parallel_step(torch_cuda, N, algo,
             if train:
                 n1.apply_adam(g1)
             a2 = native(0.05, seed=1, step=step, train=train)
-            assert torch.equal(a1, a2), step
+            assert torch.equal(a1, a2), (step, n1.split_stats(), n2.split_stats())
             if train:
                 assert torch.equal(plain.idx, native.idx) and torch.equal(plain.loss, native.loss), step
                 assert torch.equal(g1, g2), step
