@@ -79,6 +79,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---------------------------------------------------------------- the other single-GPU configurations (rank 0, N = 1 only)
+    # BASELINE.json configs[2] (Double-DQN, 4096 envs, B = 256, in fp32 and in its stated bf16) and configs[3] (prioritized replay, 1 M-slot
+    # SumTree in the reference's update order, 4096 envs) through the same device-resident loop (VecBrain: act -> env -> store -> sample ->
+    # train, one train step per env step), >= 100 ms timed each, median.  Reported under config.other_configs; never part of `value`.
+    # They run FIRST, while the process holds next to no streams: HIP deals streams out over a handful of hardware queues, and with the
+    # headline pipeline's streams alive the prioritized memory's side-stream pipeline measured 680 us per step here against 258 - 277
+    # in a process of its own (tools/dbg_per_slow.py; DESIGN.md section 4 "Streams").
+    other = None
+    if rank == 0 and world == 1 and not args.no_kernel_legs:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs as bc
+        other = []
+        for i in (1, 2, 3):
+            r_ = bc.gpu_row(i, 50 if i != 3 else 25, min_total=0.1)
+            other.append({"workload": r_["config"], "us_per_step": r_["us_per_step"], "env_steps_per_s": r_["env_steps_per_s"],
+                          "grad_steps_per_s": r_["grad_steps_per_s"], "dtype": "bf16" if r_["mode"] == "bf16" else "f32", "repeats": r_["repeats"]})
+        torch.cuda.synchronize()
+
     # ---------------------------------------------------------------- build the pipeline
     seed = 0
     env = VecGameState(N_ENVS, seed=seed + rank)            # envs shard by rank, own Philox streams
@@ -169,6 +187,19 @@ def main():
     dt = median(dts_full)
     ms_per_step = dt / args.steps * 1e3
     env_steps_per_s = world * N_ENVS * args.steps / dt
+    # which schedule the loop ran in: fb_vec_step's split schedule (train chain on the caller's stream BESIDE acting + env on the net's
+    # side stream; same results as one stream, bit for bit) -- how many steps took it, and how many of their minibatches could start
+    # beside their env step (the rest hold a transition the step itself appends and wait for it).  Then the same loop on ONE stream,
+    # for the record (A/B switch fb_vec_step_set_schedule; not part of `value`).
+    split_issued, split_clean = net.split_stats()             # (raises if a wait between the two streams gave up)
+    L.check(L.lib().fb_vec_step_set_schedule(0), "fb_vec_step_set_schedule")
+    for i in range(args.warmup):
+        full_step(i)
+    n_before = len(local_times)
+    dts_one = timed_repeat(full_step, args.steps, first=args.warmup, min_total=0.1)
+    del local_times[n_before:]
+    L.check(L.lib().fb_vec_step_set_schedule(1), "fb_vec_step_set_schedule")
+    one_stream_ms = median(dts_one) / args.steps * 1e3
 
     # ---------------------------------------------------------------- leg B: env only
     acts = (torch.rand(N_ENVS, device="cuda") < 0.1).to(torch.uint8)
@@ -346,7 +377,7 @@ def main():
         # (>= 256 nibble states: conv1 + conv2 + conv3 in ONE launch, conv1's output handed to conv2 in LDS; then fc1 on K slices)
         c1f, c23f = FWD_FLOP["conv1_pool_kernel"], FWD_FLOP["conv2_kernel"] + FWD_FLOP["conv3_kernel"]
         act = [(0, "conv1_sp_kernel<nib>", c1f, 2),                  # (a launch of its own only with FB_ACT_FUSED=0)
-               (1, "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 4 states per workgroup]", c1f + c23f, (2 * c1f + 3 * c23f) / (c1f + c23f)),
+               (1, "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 5 states per workgroup]", c1f + c23f, (2 * c1f + 3 * c23f) / (c1f + c23f)),
                (3, "fc1_sp_kernel", FWD_FLOP["fc1_kernel"], 3), (4, "head_kernel", FWD_FLOP["head_kernel"], 0)]
         for k, name, flop, split in act:
             us = ev_time(lambda: L.check(lib.fb_qnet_profile_kernel(scratch.h, k, R, -2, N_ENVS, L.ptr(nib), None, None, None,
@@ -470,20 +501,6 @@ def main():
             roofline["replay_gather"][b] = g_
         roofline["grad_steps_per_sec"] = round(grad_steps_per_s, 1)      # (the train-only half of BASELINE.json's metric, where the driver's record keeps it)
 
-    # ---------------------------------------------------------------- the other single-GPU configurations (rank 0, N = 1 only)
-    # BASELINE.json configs[2] (Double-DQN, 4096 envs, B = 256, in fp32 and in its stated bf16) and configs[3] (prioritized replay, 1 M-slot
-    # SumTree in the reference's update order, 4096 envs) through the same device-resident loop (VecBrain: act -> env -> store -> sample ->
-    # train, one train step per env step), >= 100 ms timed each, median.  Reported under config.other_configs; never part of `value`.
-    other = None
-    if rank == 0 and world == 1 and not args.no_kernel_legs:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_configs as bc
-        other = []
-        for i in (1, 2, 3):
-            r_ = bc.gpu_row(i, 50 if i != 3 else 25, min_total=0.1)
-            other.append({"workload": r_["config"], "us_per_step": r_["us_per_step"], "env_steps_per_s": r_["env_steps_per_s"],
-                          "grad_steps_per_s": r_["grad_steps_per_s"], "dtype": "bf16" if r_["mode"] == "bf16" else "f32", "repeats": r_["repeats"]})
-
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -533,6 +550,10 @@ def main():
             "config": {"workload": "configs[1]: 1024 vectorised envs + BrainDQN uniform replay, batch 32, fp32, per GPU",
                        "n_envs_per_gpu": N_ENVS, "batch": BATCH, "replay_slots": CAPACITY, "fc_width": 512,
                        "sampler": "cpython-mt19937 (bit-exact random.sample)", "epsilon": eps,
+                       "schedule": {"full_loop": "split: the train chain on the step's stream beside acting + env on the net's side stream, handed over through device words "
+                                                 "(fb_vec_step, include/fbdqn.h); results bit-identical to the one-stream order" if split_issued else "one stream",
+                                    "steps_split": split_issued, "minibatches_started_beside_their_env_step": split_clean,
+                                    "one_stream_ms_per_step": round(one_stream_ms, 4), "one_stream_env_steps_per_s": round(world * N_ENVS / one_stream_ms * 1e3, 1)},
                        "train_leg": "fb_train_steps(10) in one hipGraph: 10 x (random.sample -> ring-fed five-launch train step)" if graph_used else "eager",
                        "train_only": {"grad_steps_per_sec": round(grad_steps_per_s, 1), "us_per_grad_step": round(1e6 * world / grad_steps_per_s, 2),
                                       "grad_steps_per_sec_eager": round(grad_steps_eager, 1)},

@@ -71,6 +71,7 @@ SIGNATURES = {
     "fb_qnet_set_inference_dtype": [_vp, _i],
     "fb_qnet_overflow_count": [_vp, _i, _vp],
     "fb_qnet_split_stats": [_vp, _vp, _vp],
+    "fb_vec_step_set_schedule": [_i],
     "fb_qnet_set_train_dtype": [_vp, _i],
     "fb_qnet_forward": [_vp, _i, _vp, _i, _vp, _vp],
     "fb_qnet_act": [_vp, _vp, _i, _f, _u64, _u64, _vp, _vp, _vp],

@@ -130,8 +130,6 @@ struct FbSplitFlags {                          // [dev], one word per 64 bytes; 
     unsigned long long env_done, p4[7];        // the env step (with the push and the head riding in it) has retired
     unsigned clean_count;                      // minibatches that started beside their env step
     unsigned timeouts[7];                      // waits that gave up (must stay 0), per site: 0 the draw (env_done) 1 the side stream's entry (c_entry) 2 the fc1 backward launch's gate (trunk_done) 3 the conv backward launch's gate (fc1_done) 4 the Adam launch's last wait (env_done)
-    unsigned long long probe_a, p6[7], probe_b, p7[7];      // fb_split_probe's hand-shake words
-    unsigned probe_fail;
 };
 struct FbSplitCtx {
     hipStream_t tstream;                       // the side stream: acting forward + env step (the train chain stays on the caller's stream)
@@ -140,9 +138,17 @@ struct FbSplitCtx {
     // HIP multiplexes streams onto a few hardware queues and promises no concurrency between two streams: on a shared queue a kernel
     // that waits for a word a LATER launch stores would sit in front of it until its time-out.  So the pair (side stream, caller's
     // stream) shakes hands once, both ways, with 20 ms waits, before the schedule is used with it (fb_split_probe)
-    const void *probed_stream; int probed_ok; unsigned long long probe_seq;
+    const void *probed_stream; int probed_ok;
 };
 int fb_split_probe(FbSplitCtx *ctx, void *stream);      // 1: the side stream and `stream` make progress independently of each other (synchronises both, once per stream)
+// HIP deals a process's streams out over a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in turn and promises no concurrency
+// between two of them: a side stream that lands on its caller's queue runs IN LINE with it (the prioritized memory's run-ahead tree work
+// then cost configs[3] 680 us per step instead of 260), and a kernel on it that polls a word a later launch of the caller's stream
+// stores would wait until its time-out.  fb_streams_concurrent: a hand-shake both ways with 20 ms waits (synchronises both streams);
+// fb_side_stream_beside: `current` if it passes, else up to six fresh non-blocking streams of that priority (`current` is destroyed
+// when it is replaced); *ok says whether the stream returned passes.
+int fb_streams_concurrent(hipStream_t side, hipStream_t caller);
+hipStream_t fb_side_stream_beside(hipStream_t caller, int priority, hipStream_t current, int *ok);
 FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h);    // created on first use; NULL when the runtime lacks stream memory operations (the caller falls back)
 // random.sample(range(n after the coming push), batch) -> idx on `stream`, opening ctx->gate at ctx->seq when the draw is clean; 1 when launched
 int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream);

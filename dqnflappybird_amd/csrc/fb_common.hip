@@ -135,6 +135,64 @@ extern "C" int fb_train_steps(fb_replay_t replay, fb_qnet_t net, int algo, int b
     return rc;
 }
 
+// ---- do two streams make progress independently of each other?  (see fb_common.h)
+namespace {
+__global__ void probe_set_kernel(unsigned long long *flag, unsigned long long v) { fb_flag_store(flag, v); }
+__global__ void probe_wait_kernel(const unsigned long long *flag, unsigned long long v, unsigned *fail) {      // one wave, up to 20 ms
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (fb_flag_load(flag) < v) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 2000000LL) { atomicAdd(fail, 1u); break; }
+    }
+}
+struct ProbeWords { unsigned long long a, pa[7], b, pb[7]; unsigned fail; };
+ProbeWords *probe_words = nullptr;           // (one device per process: handles are per GPU, include/fbdqn.h)
+unsigned long long probe_seq = 0;
+}
+
+int fb_streams_concurrent(hipStream_t S, hipStream_t C) {
+    if (!probe_words && (hipMalloc((void **)&probe_words, sizeof(ProbeWords)) != hipSuccess || hipMemset(probe_words, 0, sizeof(ProbeWords)) != hipSuccess)) {
+        probe_words = nullptr; (void)hipGetLastError(); return 0;
+    }
+    ProbeWords *W = probe_words;
+    const unsigned long long v = ++probe_seq;
+    unsigned before = 0, after = 0;
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
+    if (hipMemcpy(&before, &W->fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    // the waiter is launched FIRST each time: on a shared queue it sits in front of the launch that would release it
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, S, (const unsigned long long *)&W->a, v, &W->fail);
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, C, &W->a, v);
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, C, (const unsigned long long *)&W->b, v, &W->fail);
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, S, &W->b, v);
+    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
+    if (hipMemcpy(&after, &W->fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return after == before;
+}
+
+hipStream_t fb_side_stream_beside(hipStream_t C, int priority, hipStream_t current, int *ok) {
+    bool good = current && fb_streams_concurrent(current, C);
+    for (int attempt = 0; !good && attempt < 6; attempt++) {
+        hipStream_t ts = nullptr;
+        if (hipStreamCreateWithPriority(&ts, hipStreamNonBlocking, priority) != hipSuccess) break;
+        if (current) { (void)hipStreamSynchronize(current); (void)hipStreamDestroy(current); }
+        current = ts;
+        good = fb_streams_concurrent(current, C);
+    }
+    (void)hipGetLastError();
+    if (ok) *ok = good ? 1 : 0;
+    return current;
+}
+
+// which schedule fb_vec_step uses where both apply: 1 (default; FB_VEC_SPLIT=0 starts the process with 0) = the split schedule
+static int fb_vec_split_flag = -1;
+static bool fb_vec_split_enabled() {
+    if (fb_vec_split_flag < 0) fb_vec_split_flag = !(getenv("FB_VEC_SPLIT") && atoi(getenv("FB_VEC_SPLIT")) == 0);
+    return fb_vec_split_flag != 0;
+}
+extern "C" int fb_vec_step_set_schedule(int split) { fb_vec_split_flag = split ? 1 : 0; return FB_OK; }
+
 // One step of the vectorised loop as a single host call: the five C-ABI calls of FlappyBirdDQN.py:72-76 back to back.
 extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo,
                            int batch, float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream) {
@@ -166,8 +224,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // against the trunk and the fc1 launch (which records the version and copies the head's parameters for the env launch's head rider)
     // -> it waits for the fc1 launch; workspaces -> the fused acting forward has its own (hf_act / hp_act); the acting forward against
     // the previous step's Adam, and against whatever else the caller's stream held at entry -> ev_entry.
-    static const bool split_on = !(getenv("FB_VEC_SPLIT") && atoi(getenv("FB_VEC_SPLIT")) == 0);      // A/B knob: 0 = one stream
-    if (split_on && train && !per && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
+    if (fb_vec_split_enabled() && train && !per && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
         hipStream_t A = reinterpret_cast<hipStream_t>(stream);       // (not fb_stream(): the light-entry test below compares fb_api_epoch with its value at the last exit)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(A, &cap);

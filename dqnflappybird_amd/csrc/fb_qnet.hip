@@ -3276,50 +3276,14 @@ FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h) {
     return c;
 }
 
-// one wave that waits up to 20 ms for *flag >= v and counts a failure otherwise
-__global__ void probe_wait_kernel(const unsigned long long *flag, unsigned long long v, unsigned *fail) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while (fb_flag_load(flag) < v) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 2000000LL) { atomicAdd(fail, 1u); break; }
-    }
-}
-
-static bool probe_once(FbSplitCtx *c, hipStream_t S, hipStream_t C) {
-    FbSplitFlags *F = c->f;
-    const unsigned long long v = ++c->probe_seq;
-    unsigned before = 0, after = 0;
-    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
-    if (hipMemcpy(&before, &F->probe_fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    // the waiter is launched FIRST each time: on a shared queue it sits in front of the launch that would release it
-    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, S, (const unsigned long long *)&F->probe_a, v, &F->probe_fail);
-    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, C, &F->probe_a, v);
-    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
-    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, C, (const unsigned long long *)&F->probe_b, v, &F->probe_fail);
-    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, S, &F->probe_b, v);
-    if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return false;
-    if (hipMemcpy(&after, &F->probe_fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return after == before;
-}
-
 int fb_split_probe(FbSplitCtx *c, void *stream) {
     if (!c || !c->tstream) return 0;
     if (c->probed_stream == stream && c->seq > 0) return c->probed_ok;
-    hipStream_t C = reinterpret_cast<hipStream_t>(stream);
-    bool ok = probe_once(c, c->tstream, C);
-    // a side stream that landed on the caller's queue: a few more tries with fresh streams (the runtime deals queues out in turn)
-    for (int attempt = 0; !ok && attempt < 6; attempt++) {
-        hipStream_t ts = nullptr;
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&ts, hipStreamNonBlocking, attempt & 1 ? (lo + hi) / 2 : lo) != hipSuccess) break;
-        (void)hipStreamSynchronize(c->tstream); (void)hipStreamDestroy(c->tstream);
-        c->tstream = ts;
-        ok = probe_once(c, ts, C);
-    }
-    (void)hipGetLastError();
-    c->probed_stream = stream; c->probed_ok = ok ? 1 : 0;
-    return c->probed_ok;
+    int lo = 0, hi = 0, ok = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return 0;
+    c->tstream = fb_side_stream_beside(reinterpret_cast<hipStream_t>(stream), lo, c->tstream, &ok);
+    c->probed_stream = stream; c->probed_ok = ok;
+    return ok;
 }
 
 int fb_split_wait(const FbSplitCtx *c, const unsigned long long *flag, unsigned long long v, void *stream) {
@@ -3569,8 +3533,10 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
                 }
             }
             const int rows_f = af.M;
-            static const int act_spw = getenv("FB_ACT_SPW") && atoi(getenv("FB_ACT_SPW")) == 5 ? 5 : 4;      // A/B knob: states per workgroup of the fused acting trunk
-            const bool spw5 = fused && (act_spw == 5 || p.split);          // (the split schedule: 1024 envs = 205 workgroups, the rest of the chip for the train chain)
+            // five states per workgroup (125 of the 128 MFMA rows; 1024 envs = 205 workgroups: alone it costs what four per workgroup on
+            // all 256 CUs cost, and in the split schedule the fifth of the chip it leaves is where the train chain runs beside it)
+            static const int act_spw = getenv("FB_ACT_SPW") && atoi(getenv("FB_ACT_SPW")) == 4 ? 4 : 5;      // A/B knob: states per workgroup of the fused acting trunk
+            const bool spw5 = fused && (act_spw == 5 || p.split);
             const dim3 gc((rows + 4) / 5), gc4(spw5 ? (rows + 4) / 5 : (rows + 3) / 4), gf(((rows_f + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
             if (nsp == 3) {
                 if (spw5) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 5, true>), gc4, dim3(512), 0, st, c23); }

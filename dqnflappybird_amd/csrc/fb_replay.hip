@@ -731,7 +731,21 @@ struct fb_replay {
     bool store_ahead;                // the tree part of the next fb_replay_push has been issued already; that push joins it
     bool upd_pending;                // a batch_update runs on the side stream (fb_replay_update_priorities_ahead): whatever touches the tree next joins it
     bool store_forked;               // the run-ahead store was ordered behind the caller's stream by an event of its own (a sample behind it needs no second one)
+    const void *side_for; bool side_checked; int side_ok; int side_prio;      // the caller's stream `side` has been checked against (fb_side_stream_beside; NULL is a stream too), the verdict, its priority
 };
+
+// The run-ahead tree work only pays when `side` really runs BESIDE the caller's stream; HIP may have put both on one hardware queue
+// (fb_common.h).  Checked once per caller's stream, with nothing of this memory in flight on `side`; a side stream that fails is
+// replaced by a fresh one (up to six tries), and if none passes the tree work stays in line.
+static bool per_side_usable(fb_replay *h, void *stream) {
+    if (!h->side) return false;
+    if (h->side_checked && h->side_for == stream) return h->side_ok != 0;
+    if (h->store_ahead || h->upd_pending) return h->side_checked && h->side_ok != 0;       // (work of this memory is on `side`: not now)
+    h->side = fb_side_stream_beside(fb_stream(stream), h->side_prio, h->side, &h->side_ok);
+    h->side_for = stream; h->side_checked = true;
+    return h->side_ok != 0;
+}
+
 
 // every entry point that reads or writes the tree on a caller's stream passes here first
 static int per_join(fb_replay *h, hipStream_t st) {
@@ -782,6 +796,7 @@ extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_repla
         // CU first -- behind them it would wait until that launch drains, and most of what it could hide would be over)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        h->side_prio = prio_hi;
         if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_store, hipEventDisableTiming) != hipSuccess ||
@@ -897,6 +912,7 @@ int fb_replay_finish_push(fb_replay_t h, void *stream) {
 int fb_replay_per_store_ahead(fb_replay_t h, void *stream) {
     // (reference-order mode only: the level-wise FB_PER_FAST store takes ~8 us, less than the two cross-stream hops cost)
     if (!h || h->P.kind != FB_REPLAY_PER || h->store_ahead || h->per_mode == FB_PER_FAST) return 0;
+    if (!per_side_usable(h, stream)) return 0;
     hipStream_t st = fb_stream(stream);
     // (behind a run-ahead batch_update the side stream is already ordered after the caller's last touch of the tree -- that update's own
     // fork -- and nothing on the caller's stream has touched the tree since: no second fork)
@@ -1100,6 +1116,7 @@ int fb_replay_update_priorities_ahead(fb_replay_t h, int batch, const int64_t *i
     if (knob == 0 || !h || h->P.kind != FB_REPLAY_PER || h->per_mode != FB_PER_EXACT || !h->side || !idx || !abs_err || batch < 1 || batch > MAXB) return 0;
     if (knob < 0 && h->P.n_envs < 4096) return 0;
     if (h->store_ahead || h->upd_pending) return 0;                        // (not in the loop's order: take the ordinary path)
+    if (!per_side_usable(h, stream)) return 0;
     hipStream_t st = fb_stream(stream);
     if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return 0;
     if (launch_per_update(h, batch, idx, const_cast<float *>(abs_err), nullptr, 0, h->side) != FB_OK ||

@@ -254,5 +254,7 @@ class VecBrain:
                 ep, ssum, smax, pipes = self.stats.tolist()      # the only host sync of the loop, once per log line
                 if hasattr(self.net, "check_range"):
                     self.net.check_range()                       # (the same sync: an activation beyond the two-plane fp16 range raises here)
+                if hasattr(self.net, "split_stats"):
+                    self.net.split_stats()                       # (... and so does a wait between the two streams of fb_vec_step's split schedule that gave up)
                 print(f"TIMESTEP {self.timeStep} / ENVS {self.n} / EPSILON {self.epsilon:.6f} / GAME_TIMES {ep} / "
                       f"MEAN_SCORE {ssum / max(ep, 1):.3f} / MAX_SCORE {smax} / PIPES {pipes} / LOSS {loss:.6g}", flush=True)

@@ -27,7 +27,7 @@
  *   FB_VEC_HEAD_RIDER=0       fb_vec_step: head_kernel as its own launch instead of riding in the env launch
  *   FB_VEC_SAMPLE_RIDER=0     fb_vec_step: random.sample as its own launch instead of riding in the env launch
  *   FB_VEC_SPLIT=0            fb_vec_step keeps acting + env on the caller's stream in front of the train step instead of beside it on a second stream
- *   FB_ACT_SPW=5              five states per workgroup of the fused acting trunk also outside the split schedule (default 4)
+ *   FB_ACT_SPW=4              four states per workgroup of the fused acting trunk outside the split schedule (default 5)
  *   FB_VEC_RING=0             fb_vec_step trains through fb_replay_gather + fb_qnet_train_step (u8 minibatch) instead of from the ring
  *   FB_TRAIN_STEPS_GATHER=1   the same for fb_train_steps
  *   FB_BW_MERGED=0            small-batch conv backward as two launches (conv_bx, conv_dw21) instead of conv_bw_kernel
@@ -370,6 +370,9 @@ typedef struct {
  * FB_VEC_SPLIT=0 keeps the whole step on `stream`.
  *   fb_qnet_split_stats -> [host] steps issued that way / how many of their minibatches started beside the env step (synchronous). */
 int fb_qnet_split_stats(fb_qnet_t net, int64_t *steps_host, int64_t *clean_host);
+/* Process-wide A/B switch of the above (both schedules give the same results): split = 0 keeps every later fb_vec_step on one stream,
+ * 1 (the default; the environment variable FB_VEC_SPLIT=0 starts the process with 0) takes the split schedule where it applies. */
+int fb_vec_step_set_schedule(int split);
 int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, const fb_step_buffers *b, int n_envs, int algo, int batch,
                 float epsilon, uint64_t seed, uint64_t step, int train, double gamma, void *stream);
 

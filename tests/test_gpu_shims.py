@@ -303,6 +303,49 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("N,algo,B,steps", [(1024, "dqn", 32, 400), (512, "double", 64, 200), (4096, "nature", 32, 120)])
+def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B, steps):
+    """fb_vec_step's split schedule (train chain on the caller's stream beside acting + env on the net's side stream, handed over through
+    device words) against the SAME loop kept on one stream (fb_vec_step_set_schedule(0)), two pipelines stepped alternately: actions,
+    indices and loss at every step, parameters / Adam slots / env states / ring contents at the end, bit for bit -- over enough steps
+    that both kinds of minibatch occur many times (started beside the env step; waited for it because a transition of the step itself
+    was drawn), with target syncs on the caller's stream in between (ordered against the train chain by stream order alone)."""
+    torch = torch_cuda
+    from dqnflappybird_amd import _lib as L
+    from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay, VecStep
+
+    def make():
+        env, rep, net = VecGameState(N, seed=11), VecReplay(60000, N), QNet(max_batch=max(N, B))
+        rep.seed(4, "cpython"); net.init_params(5, which=0); net.init_params(6, which=1)
+        nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
+        return env, rep, net, nib, VecStep(env, rep, net, B, algo)
+
+    e1, r1, n1, nib1, one = make()
+    e2, r2, n2, nib2, two = make()
+    try:
+        for step in range(steps):
+            train = step >= 4
+            if algo != "dqn" and train and step % 25 == 0:
+                n1.sync_target(); n2.sync_target()
+            L.check(L.lib().fb_vec_step_set_schedule(0), "schedule")
+            a1 = one(0.05, seed=2, step=step, train=train).clone()
+            L.check(L.lib().fb_vec_step_set_schedule(1), "schedule")
+            a2 = two(0.05, seed=2, step=step, train=train)
+            assert torch.equal(a1, a2), step
+            if train:
+                assert torch.equal(one.idx, two.idx) and torch.equal(one.loss, two.loss), step
+    finally:
+        L.check(L.lib().fb_vec_step_set_schedule(1), "schedule")
+    assert (e1.get_state() == e2.get_state()).all() and torch.equal(nib1, nib2)
+    assert torch.equal(n1.store_params(), n2.store_params()) and torch.equal(n1.store_params(1), n2.store_params(1))
+    (m1, v1, p1), (m2, v2, p2) = n1.adam_state(), n2.adam_state()
+    assert torch.equal(m1, m2) and torch.equal(v1, v2) and np.array_equal(p1, p2)
+    assert np.array_equal(r1.state_blob(), r2.state_blob())
+    assert n1.split_stats() == (0, 0)
+    issued, clean = n2.split_stats()                      # (raises if a wait between the two streams gave up)
+    assert issued == steps - 4 and 0 < clean < issued, (issued, clean)
+
+
 @pytest.mark.parametrize("algo,B,dtype", [("dqn", 32, "f32"), ("nature", 17, "f32"), ("double", 64, "f32"), ("double", 256, "f32"),
                                           ("nature", 32, "bf16"), ("double", 160, "bf16")])
 def test_train_from_replay_equals_gather_plus_train_step(torch_cuda, algo, B, dtype):

@@ -53,11 +53,12 @@ def run(n_envs, lr, steps, window, algo, arch, seed, out, budget_s, explore):
                 print(f"# stopped at the time budget of {budget_s} s", file=f); f.flush()
             break
     assert vb.env.error_count() == 0
+    issued, clean = vb.net.split_stats() if hasattr(vb.net, "split_stats") else (0, 0)      # (raises if a wait between the two streams of the split schedule gave up)
     first = rows[0][4]
     best = max(r[4] for r in rows)
     last = sum(r[4] for r in rows[-3:]) / len(rows[-3:])
     for f in (sys.stdout, out):
-        print(f"# summary envs {n_envs} lr {lr:g}: mean score first window {first:.3f}, best window {best:.3f}, last three windows {last:.3f}, max score of the run {max(r[5] for r in rows)}\n", file=f)
+        print(f"# summary envs {n_envs} lr {lr:g}: mean score first window {first:.3f}, best window {best:.3f}, last three windows {last:.3f}, max score of the run {max(r[5] for r in rows)}; split schedule: {issued} steps, {clean} minibatches beside their env step\n", file=f)
         f.flush()
     del vb
     torch.cuda.synchronize()

@@ -33,7 +33,7 @@ def pick(prefix, grid_pred=lambda g: True):
 small = lambda g: g < 200000
 t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, two separate rocprofv3 --pmc passes (tools/profile_round.sh); "
               "FETCH_SIZE halves wide coalesced reads on gfx950 (MI355X_MICROARCH.md), hence the factor 2; upper bound for narrow loads.",
-     "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 4 states per workgroup][act n=1024]": pick("conv23_sp_kernel<3, 4, true>"),
+     "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 5 states per workgroup][act n=1024]": pick("conv23_sp_kernel<3, 4, true>"),
      "conv1_sp_kernel<nib>[act n=1024]": pick("conv1_sp_kernel<true>"), "conv23_sp_kernel[act n=1024]": pick("conv23_sp_kernel<3, 5, false>"),
      "fc1_sp_kernel[act n=1024]": pick("fc1_sp_kernel<3>"), "head_kernel[act n=1024]": pick("head_kernel"),
      "env_kernel<true>[n=1024]": pick("env_kernel<true>"),
