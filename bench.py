@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-legs", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[3] legs (tools/profile_round.sh: the rocprofv3 kernel statistics then hold the headline workload's launches only)")
     args = ap.parse_args()
 
     import torch
@@ -87,7 +88,7 @@ def main():
     # headline pipeline's streams alive the prioritized memory's side-stream pipeline measured 680 us per step here against 258 - 277
     # in a process of its own (tools/dbg_per_slow.py; DESIGN.md section 4 "Streams").
     other = None
-    if rank == 0 and world == 1 and not args.no_kernel_legs:
+    if rank == 0 and world == 1 and not args.no_kernel_legs and not args.no_other_configs:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs as bc
         other = []

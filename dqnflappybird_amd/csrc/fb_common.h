@@ -174,6 +174,7 @@ int fb_qnet_check_step(fb_qnet_t h, int n_envs, int train_batch);
 int fb_env_num_envs(fb_env_t h);
 int fb_replay_num_envs(fb_replay_t h);
 int fb_replay_is_prioritized(fb_replay_t h);
+int fb_replay_update_priorities_keep(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream);       // in line, abs_err left untouched (fb_vec_step)
 int fb_replay_update_priorities_ahead(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream);      // batch_update on the side stream (see fb_replay.hip); 1 when issued
 int fb_replay_per_store_ahead(fb_replay_t h, void *stream);
 int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32, void *stream);      // Memory.sample behind that store, on the same stream; 1 when issued      // the tree part of the coming push, ahead of it on a side stream (see fb_replay.hip)

@@ -314,10 +314,11 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             if (rc == FB_OK) rc = fb_qnet_train_step(net, algo, batch, b->s, b->a, b->r, b->s2, b->t, b->isw32, gamma, b->loss, b->abs_err, nullptr, b->flat_grad, stream);
         }
         if (rc != FB_OK) return rc;
-        // Memory.batch_update: on the memory's side stream when it can run ahead (reference-order tree) -- b->abs_err then keeps |TD error|
-        // as the loss left it; the ordinary call adds its epsilon in place as the reference does (:147)
+        // Memory.batch_update: on the memory's side stream when it can run ahead (reference-order tree), in line otherwise; b->abs_err keeps
+        // |TD error| as the loss left it in BOTH forms (the in-place `abs_errors += epsilon` of :147 stays inside the kernel; the
+        // stand-alone fb_replay_update_priorities does it in the caller's array as the reference does)
         if (fb_replay_update_priorities_ahead(replay, batch, b->idx, b->abs_err, stream)) return FB_OK;
-        return fb_replay_update_priorities(replay, batch, b->idx, b->abs_err, nullptr, stream);
+        return fb_replay_update_priorities_keep(replay, batch, b->idx, b->abs_err, stream);
     }
     // No gather (256 envs or more).  The train step's first launch reads the sampled transitions' 1-bit frames in the ring itself
     // (conv trunk per state) and leaves a / r / t behind; the split conv planes it needs are current because the acting forward above

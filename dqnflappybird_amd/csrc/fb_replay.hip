@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024) void per_store_fast_kernel(ReplayParams P, in
 // Memory.batch_update: later duplicates win (like the reference's loop), then the ancestors level by level
 // (duplicate ancestors are refreshed redundantly with identical values)
 __global__ __launch_bounds__(256) void per_update_fast_kernel(ReplayParams P, int n, const long long *__restrict__ idx,
-                                                              float *__restrict__ abs_err, const float *__restrict__ prio) {
+                                                              float *__restrict__ abs_err, const float *__restrict__ prio, int write_back) {
     __shared__ long long ti_s[MAXB];
     const int tid = threadIdx.x;
     double ps = 0;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void per_update_fast_kernel(ReplayParams P, in
         if (prio) pf = prio[tid];
         else {
             float e = abs_err[tid] + 0.01f;
-            abs_err[tid] = e;
+            if (write_back) abs_err[tid] = e;
             const float c = e < 1.0f ? e : 1.0f;
             pf = (float)pow((double)c, (double)0.6f);
         }
@@ -1095,11 +1095,28 @@ extern "C" int fb_replay_update_priorities(fb_replay_t h, int batch, const int64
     if (rcj != FB_OK) return rcj;
     if (h->per_mode == FB_PER_FAST) {
         hipLaunchKernelGGL(per_update_fast_kernel, dim3(1), dim3(256), 0, fb_stream(stream), h->P, batch, (const long long *)idx, abs_err,
-                           priorities_or_null);
+                           priorities_or_null, 1);
         FB_LAUNCH_CHECK();
         return FB_OK;
     }
     return launch_per_update(h, batch, idx, abs_err, priorities_or_null, 1, fb_stream(stream));
+}
+
+// fb_vec_step's own Memory.batch_update when it stays in line: the same update, but the caller's abs_err array is left as the loss wrote
+// it -- |TD error| -- exactly as in the run-ahead form (fb_replay_update_priorities_ahead), so that what fb_vec_step leaves in abs_err
+// does not depend on which of the two forms the env count selected (the reference's in-place `abs_errors += epsilon`,
+// BrainPrioritizedReplyDQN.py:147, stays inside the kernel; the stand-alone fb_replay_update_priorities does it in place as before)
+int fb_replay_update_priorities_keep(fb_replay_t h, int batch, const int64_t *idx, const float *abs_err, void *stream) {
+    FB_REQUIRE(h && idx && abs_err && h->P.kind == FB_REPLAY_PER && batch >= 1 && batch <= MAXB, "fb_replay_update_priorities_keep: bad argument");
+    const int rcj = per_join(h, fb_stream(stream));
+    if (rcj != FB_OK) return rcj;
+    if (h->per_mode == FB_PER_FAST) {
+        hipLaunchKernelGGL(per_update_fast_kernel, dim3(1), dim3(256), 0, fb_stream(stream), h->P, batch, (const long long *)idx, const_cast<float *>(abs_err),
+                           (const float *)nullptr, 0);
+        FB_LAUNCH_CHECK();
+        return FB_OK;
+    }
+    return launch_per_update(h, batch, idx, const_cast<float *>(abs_err), nullptr, 0, fb_stream(stream));
 }
 
 // Memory.batch_update on the memory's SIDE stream, behind everything `stream` holds so far (reference-order mode; returns 1 when issued,

@@ -353,9 +353,10 @@ typedef struct {
      * float32 placeholder takes them (f32[B]), and the |TD errors| Memory.batch_update receives (f32[B]).
      * With the reference-order tree and 4096 envs or more Memory.batch_update of a step runs on the memory's own side stream, beside the NEXT step's acting
      * forward (its result is first needed by that step's Memory.store, which follows it there): idx and abs_err are read after
-     * fb_vec_step has returned and must stay valid -- and unwritten by the caller -- until the next call on this memory; abs_err then
-     * holds |TD error| as the loss left it (fb_replay_update_priorities, the stand-alone call, adds its 0.01 in place as the
-     * reference does, BrainPrioritizedReplyDQN.py:147).  Any later call that touches the memory's tree joins that stream first. */
+     * fb_vec_step has returned and must stay valid -- and unwritten by the caller -- until the next call on this memory.  Whichever
+     * form Memory.batch_update takes (side stream or in line), abs_err holds |TD error| as the loss left it when fb_vec_step returns
+     * (fb_replay_update_priorities, the stand-alone call, adds its 0.01 in place as the reference does,
+     * BrainPrioritizedReplyDQN.py:147).  Any later call that touches the memory's tree joins that stream first. */
     double *isw; float *isw32; float *abs_err;
 } fb_step_buffers;
 /* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net

@@ -324,7 +324,7 @@ def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B
     e2, r2, n2, nib2, two = make()
     try:
         for step in range(steps):
-            train = step >= 4
+            train = step >= 4 and step % 9 != 5            # (a step without training now and then: it takes the one-stream path, in between split ones)
             if algo != "dqn" and train and step % 25 == 0:
                 n1.sync_target(); n2.sync_target()
             L.check(L.lib().fb_vec_step_set_schedule(0), "schedule")
@@ -343,7 +343,7 @@ def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B
     assert np.array_equal(r1.state_blob(), r2.state_blob())
     assert n1.split_stats() == (0, 0)
     issued, clean = n2.split_stats()                      # (raises if a wait between the two streams gave up)
-    assert issued == steps - 4 and 0 < clean < issued, (issued, clean)
+    assert issued == sum(1 for k in range(steps) if k >= 4 and k % 9 != 5) and 0 < clean < issued, (issued, clean)
 
 
 @pytest.mark.parametrize("algo,B,dtype", [("dqn", 32, "f32"), ("nature", 17, "f32"), ("double", 64, "f32"), ("double", 256, "f32"),
@@ -511,7 +511,7 @@ def test_vec_step_prioritized_equals_the_separate_calls(torch_cuda, dp, N, steps
             assert torch.equal(idx, one.idx) and torch.equal(isw, one.isw), step
             # (|TD errors|: the stand-alone batch_update adds its 0.01 in place, :147; inside fb_vec_step it runs ahead on the memory's
             #  side stream and leaves the caller's array as the loss wrote it)
-            assert torch.equal(loss, one.loss) and (torch.equal(ae, one.abs_err + 0.01) or torch.equal(ae, one.abs_err)), step
+            assert torch.equal(loss, one.loss) and torch.equal(ae, one.abs_err + 0.01), step      # (fb_vec_step leaves |TD error| as the loss wrote it, whichever form its batch_update took; the stand-alone call adds the reference's 0.01 in place)
     assert (e1.get_state() == e2.get_state()).all() and torch.equal(nib1, nib2)
     assert torch.equal(n1.store_params(), n2.store_params())
     b1, b2 = r1.state_blob(), r2.state_blob()

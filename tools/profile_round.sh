@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r03}
 O=$R/gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 $R/bench.py --no-cpu-baseline > $O/${T}_bench_under_rocprof.json 2> $O/${T}_stats.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 $R/bench.py --no-cpu-baseline --no-other-configs > $O/${T}_bench_under_rocprof.json 2> $O/${T}_stats.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_pmc_fetch -- python3 $R/tools/prof_bench_kernels.py > /dev/null 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_pmc_write -- python3 $R/tools/prof_bench_kernels.py > /dev/null 2>&1 || exit 1
 cd $R

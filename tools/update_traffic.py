@@ -7,7 +7,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def mean_counter(dirpat, cname):
-    f = sorted(glob.glob(dirpat + "/**/*counter_collection.csv", recursive=True))[-1]
+    import os
+    f = max(glob.glob(dirpat + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)      # (the newest pass: gpurun_out/ keeps earlier ones)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == cname:
@@ -33,7 +34,7 @@ def pick(prefix, grid_pred=lambda g: True):
 small = lambda g: g < 200000
 t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, two separate rocprofv3 --pmc passes (tools/profile_round.sh); "
               "FETCH_SIZE halves wide coalesced reads on gfx950 (MI355X_MICROARCH.md), hence the factor 2; upper bound for narrow loads.",
-     "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 5 states per workgroup][act n=1024]": pick("conv23_sp_kernel<3, 4, true>"),
+     "conv23_sp_kernel<C1>[conv1 + pool + conv2 + conv3, 5 states per workgroup][act n=1024]": pick("conv23_sp_kernel<3, 5, true>"),
      "conv1_sp_kernel<nib>[act n=1024]": pick("conv1_sp_kernel<true>"), "conv23_sp_kernel[act n=1024]": pick("conv23_sp_kernel<3, 5, false>"),
      "fc1_sp_kernel[act n=1024]": pick("fc1_sp_kernel<3>"), "head_kernel[act n=1024]": pick("head_kernel"),
      "env_kernel<true>[n=1024]": pick("env_kernel<true>"),
@@ -44,6 +45,8 @@ t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, two sepa
      "fc1_bwd2_kernel": pick("fc1_bwd2_kernel"),
      "conv_bx_kernel[conv3^T / conv2^T chain + conv3 dW + Adam of W_fc1 (HBM part priced)]": pick("conv_bx_kernel<3>"),
      "conv_dw21_kernel[gathered minibatch]": pick("conv_dw21_kernel<2, false>"), "conv_dw21_kernel<ring>": pick("conv_dw21_kernel<2, true>"),
+     "conv_bw_kernel[gathered minibatch: per-sample conv3^T / conv2^T chain + conv3 / conv2 / conv1 dW + Adam of W_fc1 (HBM part priced)]": pick("conv_bw_kernel<3, false>"),
+     "conv_bw_kernel<ring>[per-sample conv3^T / conv2^T chain + conv3 / conv2 / conv1 dW; Adam of W_fc1 rides (22.9 MB)]": pick("conv_bw_kernel<3, true>"),
      "adam_fused_kernel[all but W_fc1; emits the conv planes]": pick("adam_fused_kernel"),
      "gather_kernel<false>[B=32]": pick("gather_kernel<false>", lambda g: g < 100000),
      "gather_kernel<false>[B=256]": pick("gather_kernel<false>", lambda g: 100000 < g < 1000000),
