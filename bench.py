@@ -501,6 +501,19 @@ def main():
                 g_["bound"] = "latency (1 us of traffic in a dependent launch; an EMPTY launch costs 2.8-3.3 us here, tools/mb/mb_launch.hip): the fractions are reported, not claimed"
             roofline["replay_gather"][b] = g_
         roofline["grad_steps_per_sec"] = round(grad_steps_per_s, 1)      # (the train-only half of BASELINE.json's metric, where the driver's record keeps it)
+        # `us` above is the kernel ALONE on its launch stream (HIP events).  In the measured loop it runs on the net's side stream beside
+        # the train chain (split schedule) and both slow each other: the committed rocprofv3 --kernel-trace --stats summary of this command
+        # (tools/profile_round.sh) averages its in-loop and its isolated launches -- reported beside the isolated figure, same flop count
+        spath = os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")
+        if os.path.exists(spath) and dom["kernel"].startswith("conv23_sp_kernel<C1>"):
+            import csv
+            for row in csv.DictReader(open(spath)):
+                if "conv23_sp_kernel<3, 5, true>" in row["Name"]:
+                    avg = float(row["AverageNs"]) / 1e3
+                    roofline["rocprof_summary"] = {"file": "profiles/r04_kernel_stats.csv", "calls": int(row["Calls"]), "avg_us": round(avg, 3),
+                                                   "frac": round(dom["frac"] * dom["us"] / avg, 5),
+                                                   "note": "in-loop launches (beside the train chain, ~33 us) and isolated ones (~29 us) averaged"}
+                    break
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None

@@ -116,8 +116,9 @@ int fb_replay_ring_src(fb_replay_t h, int batch, const int64_t *idx, uint8_t *a,
 // fb_qnet_train_step on such a minibatch (isw / abs_err: the prioritized step's importance weights in, |TD errors| out; else NULL).  The split conv planes of both nets must be current: true
 // after an acting forward of >= 256 states in the same stream order (fb_vec_step), which is the only caller.
 // rider: random.sample for the NEXT step in the conv3 backward launch (fb_train_steps), or NULL.
-// split (the split schedule's train chain, or NULL): the trunk waits at the gate, the conv backward launch (W_fc1's Adam span rides there) for
-// ev_trunk, the Adam launch for ev_fc1, and the Adam launch's last workgroup stores adone
+// split (the split schedule's train chain, or NULL): the fc1 backward launch gets a gate workgroup waiting for trunk_done (W_fc1's Adam span
+// rides in the launch behind it), the conv backward launch one waiting for fc1_done (the Adam launch follows), and the Adam launch's
+// last thread waits for env_done
 int fb_qnet_train_step_ring(fb_qnet_t h, int algo, int batch, const FbRingSrc *ring, const float *isw, double gamma, float *loss,
                             float *abs_err, float *flat_grad, void *stream, const FbSampleRider *rider = nullptr, const struct FbSplitCtx *split = nullptr);
 // The split schedule of fb_vec_step (fb_common.hip): the train step of a vector step on a stream of its own BESIDE the acting forward and
@@ -180,8 +181,7 @@ int fb_replay_per_store_ahead(fb_replay_t h, void *stream);
 int fb_replay_sample_ahead(fb_replay_t h, int batch, int64_t *idx, double *isw, float *isw32, void *stream);      // Memory.sample behind that store, on the same stream; 1 when issued      // the tree part of the coming push, ahead of it on a side stream (see fb_replay.hip)
 int fb_env_can_carry_head(fb_env_t h);        // 1 when an env workgroup of the step launch has a wave per env it walks (<= 4 envs per workgroup)
 // fb_qnet_act_nib without its last launch: conv1 .. fc1 are launched, *head describes the head_kernel work left over
-// split (or NULL): the split schedule's context -- five states per trunk workgroup (1024 envs: 205 workgroups, a fifth of the chip left to the
-// train chain), ev_trunk / ev_fc1 recorded behind the trunk / the fc1 launch
+// split (or NULL): the split schedule's context -- the fc1 launch stores trunk_done on arrival (the trunk in front of it has retired)
 int fb_qnet_act_nib_rider(fb_qnet_t h, const uint8_t *nib_states, int n, float epsilon, uint64_t seed, uint64_t step,
                           uint8_t *actions, FbHeadRider *head, void *stream, const FbSplitCtx *split = nullptr);
 // the rider for the frame / scalar part of "fb_replay_push" (returns 1, fills *push and COUNTS the push: the env launch that carries it

@@ -7,7 +7,6 @@
 #include "fb_common.h"
 
 thread_local char fb_err_buf[512] = "";
-unsigned long long fb_api_epoch = 0;
 
 int fb_set_error(int code, const char *fmt, ...) {
     va_list ap;
@@ -215,17 +214,18 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
     // ---- The split schedule (uniform memory, small batches): act(k) and train(k) of the reference's loop BOTH read the weights Adam(k - 1)
     // left -- what orders them is the replay append between them (FlappyBirdDQN.py:72-76, BrainDQN.py:236-240), and that only matters when
     // the minibatch holds one of the n_envs transitions this very step appends (32 draws from a million slots: ~3 % of the steps).  So
-    // the train chain goes to a stream of its own: the draw (its population size is known on the host) decides on the device whether it is
-    // clean and, if so, opens the gate the chain waits at -- otherwise the caller's stream opens it behind the env step, and the step runs
-    // in the old order.  Same kernels, same inputs, same results bit for bit (the tests that pin fb_vec_step to the separate calls run
-    // through here); the acting trunk takes five states per workgroup so that a fifth of the chip is free for the chain beside it.
+    // acting + env go to a second stream beside the train chain; the draw (its population size is known on the host) decides on the
+    // device whether the minibatch is clean, and waits for the env step itself when it is not -- the step then runs in the old order.
+    // Same kernels, same inputs, same results bit for bit (the tests that pin fb_vec_step to the separate calls run through here); the
+    // acting trunk's five states per workgroup leave a fifth of the chip to the chain beside it.
     // Hazards between the two streams, and what covers each: W_fc1's Adam span (conv backward launch) against the trunk's riding re-split
-    // of W_fc1's planes -> that launch waits for the trunk; the Adam launch (conv planes, biases, head parameters, the version word)
-    // against the trunk and the fc1 launch (which records the version and copies the head's parameters for the env launch's head rider)
-    // -> it waits for the fc1 launch; workspaces -> the fused acting forward has its own (hf_act / hp_act); the acting forward against
-    // the previous step's Adam, and against whatever else the caller's stream held at entry -> ev_entry.
+    // of W_fc1's planes -> the launch in front of it does not retire before the trunk has; the Adam launch (conv planes, biases, head
+    // parameters, the version word) against the trunk and the fc1 launch (which records the version and copies the head's parameters
+    // for the env launch's head rider) -> the launch in front of it does not retire before the fc1 launch has; workspaces -> the fused
+    // acting forward has its own (hf_act / hp_act); the acting forward against the previous step's Adam and whatever else the caller's
+    // stream held at entry -> c_entry.
     if (fb_vec_split_enabled() && train && !per && n_envs >= 256 && batch < 256 && fb_env_can_carry_head(env) && fb_qnet_num_actions(net) == 2) {
-        hipStream_t A = reinterpret_cast<hipStream_t>(stream);       // (not fb_stream(): the light-entry test below compares fb_api_epoch with its value at the last exit)
+        hipStream_t A = fb_stream(stream);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(A, &cap);
         FbSampleRider probe;
@@ -242,9 +242,10 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             //     previous Adam and everything else the caller's stream held are done (its reads of the previous step's rewards included);
             //   the acting forward's fc1 launch stores trunk_done, a one-thread launch behind it fc1_done, one behind the env launch env_done;
             //   the draw does not retire before env_done (of the previous step: nothing else orders `stream` behind that push; of this step
-            //     when the draw was not clean) -- one wave, so that nothing that spins holds what the kernels it waits for need --, the
-            //     Adam span's stores wait for trunk_done, the Adam launch's stores for fc1_done, and the Adam launch does not retire
-            //     before env_done: on return every result of the step is ordered on `stream` as before.
+            //     when the draw was not clean) -- one wave, so that nothing that spins holds what the kernels it waits for need --; a gate
+            //     workgroup at the end of the fc1 backward launch waits for trunk_done (W_fc1's Adam span rides in the next launch), one at
+            //     the end of the conv backward launch for fc1_done (Adam follows), and the Adam launch's last thread for env_done: on
+            //     return every result of the step is ordered on `stream` as before.
             hipStream_t C = A, S = sc->tstream;
             FbSplitFlags *F = sc->f;
             sc->seq += 1;

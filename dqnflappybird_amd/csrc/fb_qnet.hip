@@ -3437,8 +3437,8 @@ struct Plan {
     const FbSampleRider *sample_rider;       // train plan: random.sample for the next step rides in the conv3 backward launch
     const FbGatherRider *gather_rider;       // ... and its minibatch gather in the Adam launch
     const FbRingSrc *ring;                   // the minibatch lives in the replay's frame ring (no gathered copies): conv trunk in one launch
-    // the split schedule.  Acting plan: five states per trunk workgroup, events behind the trunk / fc1 launches.  Train plan: the trunk
-    // waits at the gate, the conv backward launch (W_fc1's Adam span) for ev_trunk, the Adam launch for ev_fc1 and stores adone
+    // the split schedule (fb_common.hip).  Acting plan: the fc1 launch stores trunk_done.  Train plan: gate workgroups in the fc1 backward
+    // launch (trunk_done) and the conv backward launch (fc1_done), the Adam launch's last thread waits for env_done
     const FbSplitCtx *split;
 };
 
