@@ -145,7 +145,19 @@ __global__ void probe_wait_kernel(const unsigned long long *flag, unsigned long 
         if (wall_clock64() - t0 > 2000000LL) { atomicAdd(fail, 1u); break; }
     }
 }
-struct ProbeWords { unsigned long long a, pa[7], b, pb[7]; unsigned fail; };
+// the dispatch test below: a launch with far more workgroups than fit at once (60 KB of LDS each: two per CU) keeps its queue's dispatcher
+// busy for its whole length; every workgroup stamps the 100 MHz clock on arrival (min) and on leaving (max)
+__global__ __launch_bounds__(64) void probe_hold_kernel(unsigned long long *first, unsigned long long *last, long long ticks) {
+    __shared__ char pad[60000];
+    pad[threadIdx.x * 900] = 0;
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    atomicMin(first, (unsigned long long)t0);
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+    atomicMax(last, (unsigned long long)wall_clock64() + (pad[0] ? 1 : 0));
+}
+__global__ void probe_stamp_kernel(unsigned long long *when) { *when = (unsigned long long)wall_clock64(); }
+struct ProbeWords { unsigned long long a, pa[7], b, pb[7]; unsigned fail; unsigned pad; unsigned long long first, last, when, first2, last2; };
 ProbeWords *probe_words = nullptr;           // (one device per process: handles are per GPU, include/fbdqn.h)
 unsigned long long probe_seq = 0;
 }
@@ -167,7 +179,48 @@ int fb_streams_concurrent(hipStream_t S, hipStream_t C) {
     hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, S, &W->b, v);
     if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
     if (hipMemcpy(&after, &W->fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return after == before;
+    if (after != before) return 0;
+    // ... and are they DISPATCHED beside each other?  Two queues on one pipe of the command processor take turns per launch: while the
+    // caller's stream is handing out a grid that does not fit at once, nothing of the side stream starts -- both make progress (the
+    // hand-shake above passes) and every kernel of the pair runs at a fraction of its speed (a vector step of 4096 envs: 478 us instead
+    // of 204, tools/dbg_per_slow.py D7).  Test: a one-wave launch on the side stream issued right behind a 2048-workgroup launch of ~35 us
+    // on the caller's must start in that launch's first half; best of three (a host hiccup between the two launches only delays it).
+    double best = 1e9;
+    for (int trial = 0; trial < 3 && best >= 0.5; trial++) {
+        const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+        if (hipMemcpy(&W->first, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return 0;
+        hipLaunchKernelGGL(probe_hold_kernel, dim3(2048), dim3(64), 0, C, &W->first, &W->last, 800LL);
+        hipLaunchKernelGGL(probe_stamp_kernel, dim3(1), dim3(1), 0, S, &W->when);
+        if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
+        unsigned long long st[3];
+        if (hipMemcpy(st, &W->first, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        if (st[1] <= st[0]) return 0;
+        const double frac = st[2] <= st[0] ? 0.0 : (double)(st[2] - st[0]) / (double)(st[1] - st[0]);
+        if (frac < best) best = frac;
+    }
+    // ... and the other way round: ONE long-running workgroup on the side stream (the prioritized memory's tree kernels are exactly that, on a
+    // highest-priority stream) must not throttle the hand-out of a wide launch on the caller's (the same symptom, same script, configs[3]:
+    // 689 us per step instead of 258): the wide launch beside it may take at most 1.6 x + 3 us of what it takes alone; best of three
+    double worst_ratio = 1e9, alone_us = 0, beside_us = 0;
+    for (int trial = 0; trial < 3 && worst_ratio >= 1.6; trial++) {
+        unsigned long long st[5];
+        const unsigned long long init[5] = {~0ull, 0ull, 0ull, ~0ull, 0ull};
+        if (hipMemcpy(&W->first, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return 0;
+        hipLaunchKernelGGL(probe_hold_kernel, dim3(2048), dim3(64), 0, C, &W->first, &W->last, 200LL);
+        if (hipStreamSynchronize(C) != hipSuccess || hipMemcpy(st, &W->first, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess || st[1] <= st[0]) return 0;
+        const double alone = (double)(st[1] - st[0]) / 100.0;
+        if (hipMemcpy(&W->first, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return 0;
+        hipLaunchKernelGGL(probe_hold_kernel, dim3(1), dim3(64), 0, S, &W->first2, &W->last2, 8000LL);        // one workgroup, 80 us
+        hipLaunchKernelGGL(probe_hold_kernel, dim3(2048), dim3(64), 0, C, &W->first, &W->last, 200LL);
+        if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
+        if (hipMemcpy(st, &W->first, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess || st[1] <= st[0]) return 0;
+        const double beside = (double)(st[1] - st[0]) / 100.0, ratio = (beside - 3.0) / alone;
+        if (ratio < worst_ratio) { worst_ratio = ratio; alone_us = alone; beside_us = beside; }
+    }
+    if (getenv("FB_SIDE_PROBE_DEBUG"))
+        fprintf(stderr, "[fb] side stream %p beside %p: a launch on it started %.2f of the way through a long launch on the caller's; a wide launch on the caller's took %.1f us beside "
+                        "a long workgroup on it, %.1f alone\n", (void *)S, (void *)C, best, beside_us, alone_us);
+    return best < 0.5 && worst_ratio < 1.6;
 }
 
 hipStream_t fb_side_stream_beside(hipStream_t C, int priority, hipStream_t current, int *ok) {

@@ -37,6 +37,7 @@
  *   FB_PER_UPDATE_AHEAD=0|1   Memory.batch_update in line / on the side stream whatever the env count (default: ahead from 4096 envs on)
  *   FB_ENV_GRID_CAP=n, FB_ENV_GRID=n    env workgroups before they stride over envs
  *   FB_ABORT_LOG=path         file the SIGABRT hook appends the native back-trace to (fb_debug_abort_backtrace)
+ *   FB_SIDE_PROBE_DEBUG=1     print what the side-stream checks measured (fb_streams_concurrent, csrc/fb_common.hip) to stderr
  * The Python side reads FB_LIB (another build of this library), FB_DP_NATIVE / FB_DP_OVERLAP (which data-parallel path, dist.py).
  * Modes that DO change results (FB_PER_FAST, the train dtype, pipelined acting) are API calls below, never variables.
  */

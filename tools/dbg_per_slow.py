@@ -42,4 +42,4 @@ if mode.startswith("D"):   # k live streams created first: does the prioritized 
         with torch.cuda.stream(s_):
             torch.zeros(8, device="cuda").add_(1)
     torch.cuda.synchronize()
-    row(3)
+    row(int(os.environ.get("DBG_ROW", "3")))
