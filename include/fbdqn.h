@@ -360,17 +360,20 @@ typedef struct {
      * BrainPrioritizedReplyDQN.py:147).  Any later call that touches the memory's tree joins that stream first. */
     double *isw; float *isw32; float *abs_err;
 } fb_step_buffers;
-/* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net
- * and a stream that is not being captured, fb_vec_step keeps the train step on `stream` and puts the acting forward and the env step
- * on a stream of the net's own BESIDE it: both read the weights the previous step's Adam left, and the minibatch depends on the env step only when it holds one
- * of the n_envs transitions this very step appends -- the draw decides that on the device and the chain then waits for the env step
- * (the chains hand over through device words that kernels store and poll -- every wait bounded at 0.2 s and counted; ~3 % of the steps
- * wait at 1024 envs / 1 M slots).  Results are those of the one-stream order bit
- * for bit.  On return everything the step produced is ordered on `stream`, so callers need not know -- with one exception: a step that
- * exports its gradient (flat_grad) is completed by fb_qnet_apply_adam / fb_dist_reduce_apply on the same stream, and only behind THAT call
- * is `stream` ordered behind the step's env launch (actions, rewards, terminals, scores, frame bits).
- * FB_VEC_SPLIT=0 keeps the whole step on `stream`.
- *   fb_qnet_split_stats -> [host] steps issued that way / how many of their minibatches started beside the env step (synchronous). */
+/* The split schedule.  For a uniform memory with the CPython generator, 256 <= n_envs <= 8192, batch < 256, a 2-action net and a stream
+ * that is not being captured, fb_vec_step keeps the train step on `stream` and puts the acting forward and the env step on a stream of the
+ * net's own BESIDE it: in the reference's loop both read the weights the previous step's Adam left (FlappyBirdDQN.py:72-76), and the
+ * minibatch depends on the env step only when it holds one of the n_envs transitions this very step appends -- the draw decides that on
+ * the device and then waits for the env step itself (~3 % of the steps at 1024 envs / 1 M slots).  The two chains hand over through
+ * device words that kernels store and single waves poll; every wait is bounded at 0.2 s and counted.  Results are those of the
+ * one-stream order bit for bit.
+ * On return everything the step produced is ordered on `stream`, so callers need not know -- with one exception: a step that exports
+ * its gradient (flat_grad) is completed by fb_qnet_apply_adam / fb_dist_reduce_apply on the same stream, and only behind THAT call is
+ * `stream` ordered behind the step's env launch (actions, rewards, terminals, scores, frame bits).
+ * The first call with a given `stream` checks that the net's side stream really runs beside it (HIP may map both to one hardware queue
+ * or pipe): it synchronises both streams a few times, ~1 ms, once; if no side stream passes, the step stays on one stream.
+ *   fb_qnet_split_stats -> [host] steps issued that way / how many of their minibatches started beside the env step (synchronous);
+ *                          FB_ERR_INVALID with the per-site counts if any wait between the chains gave up. */
 int fb_qnet_split_stats(fb_qnet_t net, int64_t *steps_host, int64_t *clean_host);
 /* Process-wide A/B switch of the above (both schedules give the same results): split = 0 keeps every later fb_vec_step on one stream,
  * 1 (the default; the environment variable FB_VEC_SPLIT=0 starts the process with 0) takes the split schedule where it applies. */
