@@ -2975,7 +2975,7 @@ __global__ void slab_fold_kernel(const float *__restrict__ sub, int nsub, int fo
 // A chunk is sixteen loads in flight at once from clamped addresses, masked by selects; the chunks are independent, so the Adam kernel
 // gives each to its own lane (per-sample slabs: z = 32 / 64 is one round trip there, not two / four; thirty-two loads in flight on
 // ONE lane -- 168 registers -- took that kernel from 7.3 to 12.0 us in situ, profiles/r04_notes.md).
-constexpr int SLAB_CHUNK = 16, SLAB_NCH = 4;
+constexpr int SLAB_CHUNK = 16;                // (four chunks: zmax = 64 slabs)
 __device__ __forceinline__ float4 slab_chunk4(const float *__restrict__ slabs, size_t slab_stride, long long q4, int z, int c) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f), t[SLAB_CHUNK];
     const int s0 = c * SLAB_CHUNK;
