@@ -100,7 +100,9 @@ struct HeadCore {
     const float *hf; int stot, nks; float *q; int FC, A, dueling; NetOff off;
     uint8_t *actions; float epsilon; uint32_t seed_lo, seed_hi, step_lo, step_hi;
 };
-struct FbHeadRider { HeadCore c; const float *params; int on; };
+// on_arrival (split schedule, or NULL): a word the launch that carries the rider stores when it arrives -- the launch in front of it (the
+// acting forward's fc1 launch) has retired then
+struct FbHeadRider { HeadCore c; const float *params; int on; unsigned long long *on_arrival; unsigned long long arrival_val; };
 // fb_replay_gather as a rider of another module's launch (fb_gather.h; B == 0: no rider): what the kernel needs of the ring
 struct FbGatherCtx {
     long long cap; int n_envs, t_f, kind;

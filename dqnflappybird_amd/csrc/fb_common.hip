@@ -293,7 +293,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             // ~1 (FbSplitFlags; every wait is bounded):
             //   S's first launch is one wave waiting for c_entry: the draw -- this call's first launch on `stream` -- has started, so the
             //     previous Adam and everything else the caller's stream held are done (its reads of the previous step's rewards included);
-            //   the acting forward's fc1 launch stores trunk_done, a one-thread launch behind it fc1_done, one behind the env launch env_done;
+            //   the acting forward's fc1 launch stores trunk_done on arrival, the env launch behind it fc1_done, a one-thread launch behind that env_done;
             //   the draw does not retire before env_done (of the previous step: nothing else orders `stream` behind that push; of this step
             //     when the draw was not clean) -- one wave, so that nothing that spins holds what the kernels it waits for need --; a gate
             //     workgroup at the end of the fc1 backward launch waits for trunk_done (W_fc1's Adam span rides in the next launch), one at
@@ -305,7 +305,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             int rc = fb_split_wait(sc, &F->c_entry, sc->seq, S);
             FbHeadRider hrider;
             if (rc == FB_OK) rc = fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, S, sc);
-            if (rc == FB_OK) rc = fb_split_set(sc, &F->fc1_done, sc->seq, S);
+            hrider.on_arrival = &F->fc1_done; hrider.arrival_val = sc->seq;      // (the env launch is the next one on S: it stores fc1_done when it arrives)
             // (a failure from here on leaves waits behind that nothing will satisfy: they give up after 0.2 s each, the error is returned)
             if (rc != FB_OK) { (void)fb_split_set(sc, &F->c_entry, sc->seq, C); (void)hipStreamSynchronize(S); return rc; }
             if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C)) return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched");

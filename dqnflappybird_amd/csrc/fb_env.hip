@@ -162,6 +162,7 @@ __global__ __launch_bounds__(ENV_THREADS, 8) void env_kernel(EnvParams p, const 
     // fb_vec_step: the replay memory's random.sample rides as the FIRST workgroup (one wave of it).  The draw needs the
     // generator and the memory's size after the push that follows this step, not the frames produced here, and its
     // ~6 us dependent chain is shorter than this kernel -- in the push launch it was the longest chain of the launch.
+    if (STEP && head.on_arrival && blockIdx.x == 0 && threadIdx.x == 0) fb_flag_store(head.on_arrival, head.arrival_val);
     const int rid = STEP && rider.k ? 1 : 0, nblk = gridDim.x - rid, bid = (int)blockIdx.x - rid;     // workgroup 0 = the rider
     if (bid < 0) {
         static_assert(sizeof(EnvLds) >= FB_SAMPLE_LDS_WORDS * 4, "the sampler borrows the sprite tables' LDS");

@@ -3578,7 +3578,7 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
         C.seed_lo = (uint32_t)p.seed; C.seed_hi = (uint32_t)(p.seed >> 32);
         C.step_lo = (uint32_t)p.step; C.step_hi = (uint32_t)(p.step >> 32);
         // (the rider of a fused acting forward reads the head's parameters from the copy that forward's fc1 launch took: b_fc1 on)
-        if (p.head_rider) { p.head_rider->c = C; p.head_rider->params = acting_fused ? h->hp_act - h->off.bf1 : p.sl.s[0].params; p.head_rider->on = 1; }   // rides in the env launch
+        if (p.head_rider) { p.head_rider->c = C; p.head_rider->params = acting_fused ? h->hp_act - h->off.bf1 : p.sl.s[0].params; p.head_rider->on = 1; p.head_rider->on_arrival = nullptr; p.head_rider->arrival_val = 0; }   // rides in the env launch
         else hipLaunchKernelGGL(head_kernel, dim3((total + 3) / 4), dim3(256), 0, st, H);
     }
     if (p.train) {
