@@ -84,9 +84,10 @@ def main():
     # BASELINE.json configs[2] (Double-DQN, 4096 envs, B = 256, in fp32 and in its stated bf16) and configs[3] (prioritized replay, 1 M-slot
     # SumTree in the reference's update order, 4096 envs) through the same device-resident loop (VecBrain: act -> env -> store -> sample ->
     # train, one train step per env step), >= 100 ms timed each, median.  Reported under config.other_configs; never part of `value`.
-    # They run FIRST, while the process holds next to no streams: HIP deals streams out over a handful of hardware queues, and with the
-    # headline pipeline's streams alive the prioritized memory's side-stream pipeline measured 680 us per step here against 258 - 277
-    # in a process of its own (tools/dbg_per_slow.py; DESIGN.md section 4 "Streams").
+    # They run FIRST, while the process holds next to no streams.  (HIP deals streams out over a handful of hardware queues and pipes: with
+    # the headline pipeline's streams alive the prioritized memory's side stream once landed beside the caller's queue in a way that cost
+    # 680 us per step against 258 - 277; the library now checks every side stream against its caller's and replaces one that fails --
+    # DESIGN.md section 4 "Streams", tools/dbg_per_slow.py -- the order stays as the simpler guarantee.)
     other = None
     if rank == 0 and world == 1 and not args.no_kernel_legs and not args.no_other_configs:
         sys.path.insert(0, os.path.join(ROOT, "tools"))

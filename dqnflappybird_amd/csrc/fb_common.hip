@@ -198,29 +198,31 @@ int fb_streams_concurrent(hipStream_t S, hipStream_t C) {
         const double frac = st[2] <= st[0] ? 0.0 : (double)(st[2] - st[0]) / (double)(st[1] - st[0]);
         if (frac < best) best = frac;
     }
-    // ... and the other way round: ONE long-running workgroup on the side stream (the prioritized memory's tree kernels are exactly that, on a
-    // highest-priority stream) must not throttle the hand-out of a wide launch on the caller's (the same symptom, same script, configs[3]:
-    // 689 us per step instead of 258): the wide launch beside it may take at most 1.6 x + 3 us of what it takes alone; best of three
+    // ... and the other way round: while ONE long-running workgroup sits on the side stream (the prioritized memory's tree kernels are exactly
+    // that, on a highest-priority stream), a chain of small dependent launches on the caller's must keep its pace.  On a bad pairing --
+    // seen with a highest-priority side stream and seven other live streams in the process -- every launch of the caller's stream takes
+    // ~50 us whatever its size while the side stream is busy (configs[3]: 680 us per step instead of 258).  Test: eight one-wave launches
+    // back to back on the caller's stream, alone and beside an 80 us workgroup on the side stream; at most 2 x + 10 us; best of three
     double worst_ratio = 1e9, alone_us = 0, beside_us = 0;
-    for (int trial = 0; trial < 3 && worst_ratio >= 1.6; trial++) {
+    for (int trial = 0; trial < 3 && worst_ratio >= 1.0; trial++) {
         unsigned long long st[5];
         const unsigned long long init[5] = {~0ull, 0ull, 0ull, ~0ull, 0ull};
         if (hipMemcpy(&W->first, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return 0;
-        hipLaunchKernelGGL(probe_hold_kernel, dim3(2048), dim3(64), 0, C, &W->first, &W->last, 200LL);
+        for (int i = 0; i < 8; i++) hipLaunchKernelGGL(probe_hold_kernel, dim3(1), dim3(64), 0, C, &W->first, &W->last, 50LL);
         if (hipStreamSynchronize(C) != hipSuccess || hipMemcpy(st, &W->first, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess || st[1] <= st[0]) return 0;
         const double alone = (double)(st[1] - st[0]) / 100.0;
         if (hipMemcpy(&W->first, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return 0;
         hipLaunchKernelGGL(probe_hold_kernel, dim3(1), dim3(64), 0, S, &W->first2, &W->last2, 8000LL);        // one workgroup, 80 us
-        hipLaunchKernelGGL(probe_hold_kernel, dim3(2048), dim3(64), 0, C, &W->first, &W->last, 200LL);
+        for (int i = 0; i < 8; i++) hipLaunchKernelGGL(probe_hold_kernel, dim3(1), dim3(64), 0, C, &W->first, &W->last, 50LL);
         if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
         if (hipMemcpy(st, &W->first, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess || st[1] <= st[0]) return 0;
-        const double beside = (double)(st[1] - st[0]) / 100.0, ratio = (beside - 3.0) / alone;
+        const double beside = (double)(st[1] - st[0]) / 100.0, ratio = beside / (2.0 * alone + 10.0);
         if (ratio < worst_ratio) { worst_ratio = ratio; alone_us = alone; beside_us = beside; }
     }
     if (getenv("FB_SIDE_PROBE_DEBUG"))
-        fprintf(stderr, "[fb] side stream %p beside %p: a launch on it started %.2f of the way through a long launch on the caller's; a wide launch on the caller's took %.1f us beside "
+        fprintf(stderr, "[fb] side stream %p beside %p: a launch on it started %.2f of the way through a long launch on the caller's; eight small launches on the caller's took %.1f us beside "
                         "a long workgroup on it, %.1f alone\n", (void *)S, (void *)C, best, beside_us, alone_us);
-    return best < 0.5 && worst_ratio < 1.6;
+    return best < 0.5 && worst_ratio < 1.0;
 }
 
 hipStream_t fb_side_stream_beside(hipStream_t C, int priority, hipStream_t current, int *ok) {

@@ -797,7 +797,7 @@ extern "C" int fb_replay_create(int64_t capacity, int n_envs, int kind, fb_repla
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         h->side_prio = prio_hi;
-        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, h->side_prio) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_store, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess) {
