@@ -303,8 +303,9 @@ def test_vec_step_single_call_equals_separate_calls(torch_cuda, N, steps):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("N,algo,B,steps", [(1024, "dqn", 32, 400), (512, "double", 64, 200), (4096, "nature", 32, 120)])
-def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B, steps):
+@pytest.mark.parametrize("N,algo,B,steps,dtype", [(1024, "dqn", 32, 400, "f32"), (512, "double", 64, 200, "f32"), (4096, "nature", 32, 120, "f32"),
+                                                   (1024, "nature", 32, 150, "bf16")])
+def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B, steps, dtype):
     """fb_vec_step's split schedule (train chain on the caller's stream beside acting + env on the net's side stream, handed over through
     device words) against the SAME loop kept on one stream (fb_vec_step_set_schedule(0)), two pipelines stepped alternately: actions,
     indices and loss at every step, parameters / Adam slots / env states / ring contents at the end, bit for bit -- over enough steps
@@ -317,6 +318,8 @@ def test_split_schedule_equals_one_stream_over_many_steps(torch_cuda, N, algo, B
     def make():
         env, rep, net = VecGameState(N, seed=11), VecReplay(60000, N), QNet(max_batch=max(N, B))
         rep.seed(4, "cpython"); net.init_params(5, which=0); net.init_params(6, which=1)
+        if dtype == "bf16":                                 # (bf16 acting + training: the one-plane instantiations of both trunks)
+            net.set_inference_dtype("bf16"); net.set_train_dtype("bf16")
         nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
         return env, rep, net, nib, VecStep(env, rep, net, B, algo)
 
