@@ -16,6 +16,6 @@ nib = env.track_state()
 env.observe(); replay.reset(env.frame_bits)
 one = VecStep(env, replay, net, B, algo)
 train = os.environ.get("FB_TRACE_TRAIN", "1") == "1"          # 0: act -> env -> push only (W_fc1's planes never go stale)
-for step in range(150):
+for step in range(int(os.environ.get("FB_TRACE_STEPS", "150"))):      # (the split schedule's minibatches are mostly clean only once the memory holds ~300 steps)
     one(0.03, seed=0, step=step, train=train)
 torch.cuda.synchronize()
