@@ -304,13 +304,14 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             hipStream_t C = A, S = sc->tstream;
             FbSplitFlags *F = sc->f;
             sc->seq += 1;
+            // (issue order on the host: the draw first -- it heads the longer chain, and the side stream's entry wave waits for it anyway)
+            if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C)) { sc->seq -= 1; return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched"); }
             int rc = fb_split_wait(sc, &F->c_entry, sc->seq, S);
             FbHeadRider hrider;
             if (rc == FB_OK) rc = fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, S, sc);
-            hrider.on_arrival = &F->fc1_done; hrider.arrival_val = sc->seq;      // (the env launch is the next one on S: it stores fc1_done when it arrives)
             // (a failure from here on leaves waits behind that nothing will satisfy: they give up after 0.2 s each, the error is returned)
-            if (rc != FB_OK) { (void)fb_split_set(sc, &F->c_entry, sc->seq, C); (void)hipStreamSynchronize(S); return rc; }
-            if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C)) return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched");
+            if (rc != FB_OK) { (void)hipStreamSynchronize(S); return rc; }
+            hrider.on_arrival = &F->fc1_done; hrider.arrival_val = sc->seq;      // (the env launch is the next one on S: it stores fc1_done when it arrives)
             FbPushRider prider;
             fb_replay_begin_push_rider(replay, &prider);       // (counts the push: the minibatch below is addressed in the memory as it will be)
             FbRingSrc ring;
