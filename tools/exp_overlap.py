@@ -9,9 +9,10 @@ from dqnflappybird_amd import _lib as L
 from dqnflappybird_amd.vec import QNet, VecGameState, VecReplay
 lib = L.lib()
 hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-N, B, STEPS = 1024, 32, 400
-env, rep, net = VecGameState(N, seed=0), VecReplay(1_000_000, N), QNet(max_batch=N)
-rep.seed(0, "cpython"); net.init_params(0)
+N, B, STEPS = int(os.environ.get("EXP_N", "1024")), int(os.environ.get("EXP_B", "32")), 400
+ALGO = int(os.environ.get("EXP_ALGO", "0"))
+env, rep, net = VecGameState(N, seed=0), VecReplay(1_000_000, N), QNet(max_batch=max(N, B))
+rep.seed(0, "cpython"); net.init_params(0); net.sync_target()
 nib = env.track_state(); env.observe(); rep.reset(env.frame_bits)
 acts = torch.zeros(N, dtype=torch.uint8, device="cuda")
 idx = torch.zeros(B, dtype=torch.int64, device="cuda")
@@ -47,7 +48,7 @@ def act_env(st, step):
 
 def train(st):
     L.check(lib.fb_replay_sample(rep.h, B, None, P(idx), None, st), "sample")
-    L.check(lib.fb_train_from_replay(rep.h, net.h, 0, B, P(idx), None, P(a), P(r), P(t), C.c_double(0.99), P(loss), None, None, st), "train")
+    L.check(lib.fb_train_from_replay(rep.h, net.h, ALGO, B, P(idx), None, P(a), P(r), P(t), C.c_double(0.99), P(loss), None, None, st), "train")
 
 
 def run(mode):
