@@ -158,15 +158,17 @@ __global__ __launch_bounds__(64) void probe_hold_kernel(unsigned long long *firs
 }
 __global__ void probe_stamp_kernel(unsigned long long *when) { *when = (unsigned long long)wall_clock64(); }
 struct ProbeWords { unsigned long long a, pa[7], b, pb[7]; unsigned fail; unsigned pad; unsigned long long first, last, when, first2, last2; };
-ProbeWords *probe_words = nullptr;           // (one device per process: handles are per GPU, include/fbdqn.h)
+ProbeWords *probe_words[64] = {};            // per device (the current one of the calling thread)
 unsigned long long probe_seq = 0;
 }
 
 int fb_streams_concurrent(hipStream_t S, hipStream_t C) {
-    if (!probe_words && (hipMalloc((void **)&probe_words, sizeof(ProbeWords)) != hipSuccess || hipMemset(probe_words, 0, sizeof(ProbeWords)) != hipSuccess)) {
-        probe_words = nullptr; (void)hipGetLastError(); return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!probe_words[dev] && (hipMalloc((void **)&probe_words[dev], sizeof(ProbeWords)) != hipSuccess || hipMemset(probe_words[dev], 0, sizeof(ProbeWords)) != hipSuccess)) {
+        probe_words[dev] = nullptr; (void)hipGetLastError(); return 0;
     }
-    ProbeWords *W = probe_words;
+    ProbeWords *W = probe_words[dev];
     const unsigned long long v = ++probe_seq;
     unsigned before = 0, after = 0;
     if (hipStreamSynchronize(S) != hipSuccess || hipStreamSynchronize(C) != hipSuccess) return 0;
