@@ -32,7 +32,7 @@ static inline hipStream_t fb_stream(void *s) { return reinterpret_cast<hipStream
 // number).  Stores and polls are relaxed agent-scope atomics (they go to the coherent level, past the XCD's own L2); a reader that goes
 // on to READ what the other kernel wrote adds fb_flag_acquire() -- the L2s of the eight XCDs are not coherent with each other inside a
 // launch -- and the writer of such data stores the word from a kernel BEHIND the one that wrote the data (its end-of-kernel release has
-// written the data back).  Waits are bounded: after ~0.2 s a wave counts a timeout and goes on, so none can spin forever.
+// written the data back).  Waits are bounded: after ~1 s a wave counts a timeout and goes on, so none can spin forever.
 __device__ __forceinline__ unsigned long long fb_flag_load(const unsigned long long *flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_flag_store(unsigned long long *flag, unsigned long long v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_flag_acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
@@ -52,7 +52,7 @@ __device__ __forceinline__ void fb_flag_wait(const unsigned long long *flag, uns
     const long long t0 = wall_clock64();
     while (fb_flag_load(flag) < v) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 20000000LL) { atomicAdd(timeouts, 1u); break; }      // (100 MHz counter)
+        if (wall_clock64() - t0 > 100000000LL) { atomicAdd(timeouts, 1u); break; }      // (100 MHz counter)
     }
 }
 

@@ -311,7 +311,7 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             int rc = fb_split_wait(sc, &F->c_entry, sc->seq, S);
             FbHeadRider hrider;
             if (rc == FB_OK) rc = fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, S, sc);
-            // (a failure from here on leaves waits behind that nothing will satisfy: they give up after 0.2 s each, the error is returned)
+            // (a failure from here on leaves waits behind that nothing will satisfy: they give up after 1 s each, the error is returned)
             if (rc != FB_OK) { (void)hipStreamSynchronize(S); return rc; }
             hrider.on_arrival = &F->fc1_done; hrider.arrival_val = sc->seq;      // (the env launch is the next one on S: it stores fc1_done when it arrives)
             FbPushRider prider;

@@ -3305,7 +3305,7 @@ extern "C" int fb_qnet_split_stats(fb_qnet_t h, int64_t *steps_host, int64_t *cl
     FB_CHECK_HIP(hipDeviceSynchronize());
     unsigned v[8] = {0};
     FB_CHECK_HIP(hipMemcpy(v, &h->split->f->clean_count, sizeof(v), hipMemcpyDeviceToHost));
-    FB_REQUIRE(!(v[1] | v[2] | v[3] | v[4] | v[5]), "fb_qnet_split_stats: waits between the two chains of the split schedule gave up after 0.2 s (the draw %u, the side stream's entry %u, "
+    FB_REQUIRE(!(v[1] | v[2] | v[3] | v[4] | v[5]), "fb_qnet_split_stats: waits between the two chains of the split schedule gave up after 1 s (the draw %u, the side stream's entry %u, "
                "the Adam span %u, the Adam launch's stores %u, its last wait %u): the results of those steps are not to be trusted", v[1], v[2], v[3], v[4], v[5]);
     *steps_host = (int64_t)h->split->seq; *clean_host = (int64_t)v[0];
     return FB_OK;

@@ -365,7 +365,7 @@ typedef struct {
  * net's own BESIDE it: in the reference's loop both read the weights the previous step's Adam left (FlappyBirdDQN.py:72-76), and the
  * minibatch depends on the env step only when it holds one of the n_envs transitions this very step appends -- the draw decides that on
  * the device and then waits for the env step itself (~3 % of the steps at 1024 envs / 1 M slots).  The two chains hand over through
- * device words that kernels store and single waves poll; every wait is bounded at 0.2 s and counted.  Results are those of the
+ * device words that kernels store and single waves poll; every wait is bounded at 1 s and counted.  Results are those of the
  * one-stream order bit for bit.
  * On return everything the step produced is ordered on `stream`, so callers need not know -- with one exception: a step that exports
  * its gradient (flat_grad) is completed by fb_qnet_apply_adam / fb_dist_reduce_apply on the same stream, and only behind THAT call is
