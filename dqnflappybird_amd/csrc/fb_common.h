@@ -90,7 +90,7 @@ struct FbMT { uint32_t mt[624]; uint32_t idx; };
 // on arrival) and the gate of the train chain behind it: it does not retire before the env step its minibatch depends on has (the
 // previous step's when none of the drawn positions is >= newest_from, else this step's own)
 struct FbSplitFlags;
-struct FbSampleCtx { FbMT *mt; int *error; long long n; FbSplitFlags *gate; unsigned long long gate_val; long long newest_from; };
+struct FbSampleCtx { FbMT *mt; int *error; long long n; FbSplitFlags *gate; unsigned long long gate_val; long long newest_from; int wait_last_round; };
 // random.sample(range(n), k) -> out[k] as a rider of another module's launch (fb_sampler.h; k == 0: no rider)
 struct FbSampleRider { FbSampleCtx ctx; int k; long long setsize; long long *out; };
 // fc2 / dueling head + epsilon-greedy action of one state from the fc1 partial sums (fb_head.h): the acting path's last
@@ -131,6 +131,7 @@ struct FbSplitFlags {                          // [dev], one word per 64 bytes; 
     unsigned long long trunk_done, p2[7];      // the acting trunk has retired (stored by the fc1 launch behind it)
     unsigned long long fc1_done, p3[7];        // the acting forward's fc1 launch has retired
     unsigned long long env_done, p4[7];        // the env step (with the push and the head riding in it) has retired
+    unsigned long long last_round, p8[7];      // (acting trunks of more than one round of workgroups) the first workgroup of the LAST round has been placed
     unsigned clean_count;                      // minibatches that started beside their env step
     unsigned timeouts[7];                      // waits that gave up (must stay 0), per site: 0 the draw (env_done) 1 the side stream's entry (c_entry) 2 the fc1 backward launch's gate (trunk_done) 3 the conv backward launch's gate (fc1_done) 4 the Adam launch's last wait (env_done)
 };
@@ -154,7 +155,8 @@ int fb_streams_concurrent(hipStream_t side, hipStream_t caller);
 hipStream_t fb_side_stream_beside(hipStream_t caller, int priority, hipStream_t current, int *ok);
 FbSplitCtx *fb_qnet_split_ctx(fb_qnet_t h);    // created on first use; NULL when the runtime lacks stream memory operations (the caller falls back)
 // random.sample(range(n after the coming push), batch) -> idx on `stream`, opening ctx->gate at ctx->seq when the draw is clean; 1 when launched
-int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream);
+// wait_last_round: the draw also waits until the acting trunk on the side stream has placed the first workgroup of its last round
+int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream, int wait_last_round = 0);
 // one-wave launches on `stream`: wait until *flag >= v (bounded) / *flag = v behind whatever the stream holds
 int fb_split_wait(const FbSplitCtx *ctx, const unsigned long long *flag, unsigned long long v, void *stream);
 int fb_split_set(const FbSplitCtx *ctx, unsigned long long *flag, unsigned long long v, void *stream);

@@ -307,7 +307,13 @@ extern "C" int fb_vec_step(fb_env_t env, fb_replay_t replay, fb_qnet_t net, cons
             FbSplitFlags *F = sc->f;
             sc->seq += 1;
             // (issue order on the host: the draw first -- it heads the longer chain, and the side stream's entry wave waits for it anyway)
-            if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C)) { sc->seq -= 1; return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched"); }
+            // (from 4096 envs on the acting side is the longer chain by far and its trunk takes several rounds of workgroups, the last one
+            // partial -- 4096 envs: 52 of 820 -- : the train chain then starts with that last round, when most of the chip falls idle, and
+            // the full rounds run undisturbed: 205 -> 200 us per step at 4096 envs; at 2048 envs what is left of the side chain by then is
+            // shorter than the train chain, 123 -> 125, hence the threshold)
+            static const bool last_round_on = !(getenv("FB_SPLIT_LAST_ROUND") && atoi(getenv("FB_SPLIT_LAST_ROUND")) == 0);      // A/B knob
+            const int trunk_wgs = (n_envs + 4) / 5, wait_last_round = last_round_on && n_envs >= 4096 && trunk_wgs % 256 != 0;
+            if (!fb_replay_sample_gated(replay, batch, b->idx, sc, C, wait_last_round)) { sc->seq -= 1; return fb_set_error(FB_ERR_HIP, "fb_vec_step: the gated draw could not be launched"); }
             int rc = fb_split_wait(sc, &F->c_entry, sc->seq, S);
             FbHeadRider hrider;
             if (rc == FB_OK) rc = fb_qnet_act_nib_rider(net, b->nib, n_envs, epsilon, seed, step, b->actions, &hrider, S, sc);

@@ -575,6 +575,7 @@ struct C23Args {
     const uint8_t *nib; const uint16_t *w1s; const float *b1;
     const float *params; uint4 *wsp; int FC;  // ... and the riding re-split of W_fc1's planes for the fc1 launch that follows (pver != wver)
     unsigned *ovf;                           // the net's overflow word (note_overflow)
+    unsigned long long *round_flag; unsigned long long round_val; int round_blk;      // split schedule (or NULL): workgroup round_blk stores round_val on arrival
 };
 
 #ifndef C23_NO_LDSR
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(512) void conv23_sp_kernel(C23Args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w4 = wave & 3, grp = wave >> 2, hl = lane >> 5, j = lane & 31;
     const int s0 = blockIdx.x * SPW, ml = w4 * 32 + j;
     if (!C1 && a.wver && blockIdx.x == 0 && threadIdx.x == 0) { *a.wver = *a.pver; *a.wverc = *a.pver; }
+    if (C1 && a.round_flag && (int)blockIdx.x == a.round_blk && threadIdx.x == 0) fb_flag_store(a.round_flag, a.round_val);
     const int bl = ml / 25, rem = ml - bl * 25, oy = rem / 5, ox = rem - oy * 5;
     const bool rowok = ml < SPW * 25;
     int nloc = a.n - s0; if (nloc > SPW) nloc = SPW;
@@ -3305,8 +3307,8 @@ extern "C" int fb_qnet_split_stats(fb_qnet_t h, int64_t *steps_host, int64_t *cl
     FB_CHECK_HIP(hipDeviceSynchronize());
     unsigned v[8] = {0};
     FB_CHECK_HIP(hipMemcpy(v, &h->split->f->clean_count, sizeof(v), hipMemcpyDeviceToHost));
-    FB_REQUIRE(!(v[1] | v[2] | v[3] | v[4] | v[5]), "fb_qnet_split_stats: waits between the two chains of the split schedule gave up after 1 s (the draw %u, the side stream's entry %u, "
-               "the Adam span %u, the Adam launch's stores %u, its last wait %u): the results of those steps are not to be trusted", v[1], v[2], v[3], v[4], v[5]);
+    FB_REQUIRE(!(v[1] | v[2] | v[3] | v[4] | v[5] | v[6]), "fb_qnet_split_stats: waits between the two chains of the split schedule gave up after 1 s (the draw %u, the side stream's entry %u, "
+               "the fc1 backward launch's gate %u, the conv backward launch's gate %u, the Adam launch's last wait %u): the results of those steps are not to be trusted", v[1], v[2], v[3], v[4], v[5]);
     *steps_host = (int64_t)h->split->seq; *clean_host = (int64_t)v[0];
     return FB_OK;
 }
@@ -3538,6 +3540,9 @@ static int run_plan(fb_qnet *h, const Plan &p, int only, hipStream_t st) {
             static const int act_spw = getenv("FB_ACT_SPW") && atoi(getenv("FB_ACT_SPW")) == 4 ? 4 : 5;      // A/B knob: states per workgroup of the fused acting trunk
             const bool spw5 = fused && (act_spw == 5 || p.split);
             const dim3 gc((rows + 4) / 5), gc4(spw5 ? (rows + 4) / 5 : (rows + 3) / 4), gf(((rows_f + 127) / 128) * (h->FC / 64) * FC1_SP_KS);    // FC % 128 == 0 (fb_qnet_create)
+            // split schedule, more than one round of trunk workgroups (one per CU, 256 CUs) with a partial last round: that round's first
+            // workgroup says when it has been placed -- the train chain on the other stream starts then (fb_sampler.h)
+            if (fused && p.split && only < 0 && gc4.x > 256 && gc4.x % 256 != 0) { c23.round_flag = &p.split->f->last_round; c23.round_val = p.split->seq; c23.round_blk = (int)(gc4.x / 256) * 256; }
             if (nsp == 3) {
                 if (spw5) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 5, true>), gc4, dim3(512), 0, st, c23); }
                 else if (fused) { FB_K(K_CONV2) hipLaunchKernelGGL((conv23_sp_kernel<3, 4, true>), gc4, dim3(512), 0, st, c23); }      // conv1 .. conv3

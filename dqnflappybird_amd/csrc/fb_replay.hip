@@ -1001,10 +1001,10 @@ int fb_replay_sample_rider(fb_replay_t h, int batch, int64_t *idx, FbSampleRider
     return 1;
 }
 
-int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream) {
+int fb_replay_sample_gated(fb_replay_t h, int batch, int64_t *idx, const FbSplitCtx *ctx, void *stream, int wait_last_round) {
     FbSampleRider r;
     if (!h || !ctx || !fb_replay_sample_rider(h, batch, idx, &r, 1)) return 0;
-    r.ctx.gate = ctx->f; r.ctx.gate_val = ctx->seq;
+    r.ctx.gate = ctx->f; r.ctx.gate_val = ctx->seq; r.ctx.wait_last_round = wait_last_round;
     r.ctx.newest_from = r.ctx.n - h->P.n_envs;          // deque positions of the transitions the coming push appends
     hipLaunchKernelGGL(sample_gated_kernel, dim3(1), dim3(64), 0, fb_stream(stream), r);
     return hipGetLastError() == hipSuccess;

@@ -184,6 +184,10 @@ __device__ __forceinline__ void sample_cpython_body(const FbSampleCtx &P, int k,
         if (lane == 0) {
             if (!dirty) atomicAdd(&P.gate->clean_count, 1u);
             fb_flag_wait(&P.gate->env_done, dirty ? P.gate_val : P.gate_val - 1, &P.gate->timeouts[0]);
+            // an acting trunk of several rounds of workgroups (2048 envs and more): the chain behind this launch starts when the trunk's
+            // LAST round does -- that round is a partial one (4096 envs: 52 of 820 workgroups), most of the chip is idle beside it, and the
+            // full rounds before it run undisturbed
+            if (P.wait_last_round) fb_flag_wait(&P.gate->last_round, P.gate_val, &P.gate->timeouts[5]);
         }
     }
 }

@@ -27,6 +27,7 @@
  *   FB_VEC_HEAD_RIDER=0       fb_vec_step: head_kernel as its own launch instead of riding in the env launch
  *   FB_VEC_SAMPLE_RIDER=0     fb_vec_step: random.sample as its own launch instead of riding in the env launch
  *   FB_VEC_SPLIT=0            fb_vec_step keeps acting + env on the caller's stream in front of the train step instead of beside it on a second stream
+ *   FB_SPLIT_LAST_ROUND=0     split schedule at >= 4096 envs: the train chain starts with the draw instead of with the acting trunk's last round of workgroups
  *   FB_ACT_SPW=4              four states per workgroup of the fused acting trunk outside the split schedule (default 5)
  *   FB_VEC_RING=0             fb_vec_step trains through fb_replay_gather + fb_qnet_train_step (u8 minibatch) instead of from the ring
  *   FB_TRAIN_STEPS_GATHER=1   the same for fb_train_steps
